@@ -1,0 +1,242 @@
+/*
+ * scanspace.h -- C ABI of libscanspace_hip.so: the per-image correction chain of
+ * "Image Space" (hglmz/scanSpaceImageProcessor) as hand-written gfx950 HIP kernels.
+ *
+ * The reference has no FFI layer: its boundary is the Python call surface of
+ * ImageProcessor/editingTools.py and ImageProcessor/imageProcessorWorker.py.
+ * Each entry point below names the reference function(s) it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns 0 (SS_OK) or a negative ss_status; the text of the
+ *     last failure on a context is ss_last_error(ctx).
+ *   - images are interleaved RGB, C-contiguous (H, W, 3) float32; a batch is
+ *     `batch` such images of identical size, back to back.
+ *   - "*_dev" pointers are device (HBM) addresses on the context's GPU, "*_host"
+ *     pointers are ordinary host memory.  The caller owns every buffer it passes;
+ *     the library keeps no pointer after a call returns (device-pointer calls are
+ *     asynchronous on the context's stream: keep the buffers alive until
+ *     ss_ctx_sync or a stream synchronisation of your own).
+ *   - a context is not thread-safe; use one context per worker thread (the
+ *     reference runs one QRunnable / Python thread per worker:
+ *     image_space.py:3483, networkProcessor.py:2603).  Different contexts share
+ *     no mutable state.
+ */
+#ifndef SCANSPACE_H
+#define SCANSPACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ss_ctx ss_ctx;
+
+typedef enum ss_status {
+  SS_OK = 0,
+  SS_ERR_INVALID = -1,     /* bad argument / descriptor */
+  SS_ERR_HIP = -2,         /* a HIP runtime call failed */
+  SS_ERR_NOMEM = -3,       /* device or pinned allocation failed */
+  SS_ERR_UNSUPPORTED = -4  /* valid request outside what the kernels implement */
+} ss_status;
+
+/* Colour-correction expansion applied per pixel (colour.colour_correction's
+ * `method`, called from imageProcessorWorker.py:337). */
+typedef enum ss_ccm_kind {
+  SS_CCM_NONE = 0,
+  SS_CCM_CHEUNG = 1,   /* 'Cheung 2004', ccm_terms in {3,5,7,8,10,11,14,16,17,19,20,22}; the reference uses 3 */
+  SS_CCM_ROOTPOLY = 2  /* 'Finlayson 2015' root-polynomial, ccm_terms in {3,6,13,22} (degree 1..4) */
+} ss_ccm_kind;
+
+/* Output encodings of ImageCorrectionWorker.encode_image (imageProcessorWorker.py:579-602). */
+typedef enum ss_out_kind {
+  SS_OUT_F32_LINEAR = 0, /* '.exr' branch: float array unchanged */
+  SS_OUT_F32_SRGB = 1,   /* colour.cctf_encoding(x), float */
+  SS_OUT_U16_SRGB = 2,   /* np.uint16(np.clip(enc*65535, 0, 65535)) : truncation */
+  SS_OUT_U8_SRGB = 3,    /* np.uint8(np.clip(enc*255, 0, 255))      : truncation */
+  SS_OUT_U8_LINEAR = 4   /* np.uint8(np.clip(x*255, 0, 255)) without encoding: the preview array of
+                            imageProcessorWorker.py:653,922 */
+} ss_out_kind;
+
+#define SS_MAX_CCM_TERMS 22
+#define SS_MAX_GAIN_STAGES 3
+#define SS_MAX_USM_RADIUS 15 /* kernel size int(6*sigma)+1 (made odd) <= 31, i.e. sigma <= 5 */
+#define SS_NEG_PARAM_STRIDE 8 /* floats per image in a negative-parameter table */
+
+/*
+ * One fused pass over a batch.  Stages run in this order; each is skipped at its
+ * neutral setting, exactly like the reference skips the corresponding call.
+ *
+ *  1. negative inversion      editingTools.py:321,336-337
+ *        x = 1 - clip((clip(x,0,1) - p_low[c]) * inv_denom[c], 0, 1)
+ *  2. colour correction       colour.colour_correction, imageProcessorWorker.py:337
+ *        rgb = CCM(3 x terms) . expand(rgb)
+ *  3. gain stages, each `clip(rgb * gain[s][c], 0, 1)`:
+ *        exposure-normalisation multiplier   imageProcessorWorker.py:875-876
+ *        white-balance multipliers           editingTools.py:636-640
+ *        exposure 2**ev                      editingTools.py:460-466
+ *  4. shadows/highlights in CIE Lab          editingTools.py:469-544
+ *  5. unsharp mask on L                      editingTools.py:714-820
+ *  6. final clip to [0,1]                    imageProcessorWorker.py:876,894,900
+ *  7. output encoding                        imageProcessorWorker.py:579-602
+ */
+typedef struct ss_chain_desc {
+  int32_t height, width, batch;
+
+  /* 1. negative inversion */
+  int32_t neg_enabled;
+  float neg_p_low[3];          /* used when neg_params_dev == NULL */
+  float neg_inv_denom[3];      /* 1 / max(p_high - p_low, 1e-3) */
+  const float* neg_params_dev; /* device table [batch][SS_NEG_PARAM_STRIDE] = {p_low[3], inv_denom[3], 0, 0},
+                                  as written by ss_negative_params; overrides the two arrays above */
+
+  /* 2. colour correction */
+  int32_t ccm_kind;  /* ss_ccm_kind */
+  int32_t ccm_terms; /* T */
+  float ccm[3 * SS_MAX_CCM_TERMS]; /* row-major 3 x T */
+
+  /* 3. gain + clip stages */
+  int32_t n_gain_stages;              /* 0..SS_MAX_GAIN_STAGES */
+  float gain[SS_MAX_GAIN_STAGES][3];  /* per stage, per channel */
+  const float* gain0_dev;             /* optional device array [batch]: per-image factor multiplied into stage 0
+                                         (dataset exposure normalisation); needs n_gain_stages >= 1 */
+
+  /* 4. shadows / highlights (arguments of adjust_shadows_highlights_combined) */
+  int32_t sh_enabled;
+  float sh_shadow_amount;
+  float sh_highlight_amount;
+  float sh_falloff_power; /* reference default 7.0 */
+
+  /* 5. unsharp mask (arguments of adjust_sharpen) */
+  int32_t usm_enabled;
+  float usm_amount;
+  float usm_radius;    /* Gaussian sigma; kernel size int(6*sigma)+1, made odd */
+  float usm_threshold;
+
+  /* Data is CIE Lab (L 0..100) in and out: stages 4/5 skip their RGB<->Lab conversions
+   * (the `is_lab_input` branches, editingTools.py:504-506, 542-544, 741-743, 818-820).
+   * Requires ccm_kind == NONE, no negative inversion, no gain stages, F32_LINEAR output, final_clip == 0. */
+  int32_t lab_io;
+
+  /* 6./7. */
+  int32_t final_clip; /* clip to [0,1] before encoding */
+  int32_t out_kind;   /* ss_out_kind */
+} ss_chain_desc;
+
+/* ---- context ----------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` (own non-blocking stream, lazily grown workspace). */
+int ss_ctx_create(int device, ss_ctx** out_ctx);
+void ss_ctx_destroy(ss_ctx* ctx);
+/* Launch on a caller-owned hipStream_t instead of the context's own (NULL restores the own stream). */
+int ss_ctx_set_stream(ss_ctx* ctx, void* hip_stream);
+/* Block until everything queued on the context's stream has finished. */
+int ss_ctx_sync(ss_ctx* ctx);
+/* Text of the last error recorded on this context ("" if none); ctx == NULL -> last ss_ctx_create failure. */
+const char* ss_last_error(const ss_ctx* ctx);
+/* Library version string. */
+const char* ss_version(void);
+
+/* ---- correction chain -------------------------------------------------------------------- */
+
+/* Fused chain on device-resident data (asynchronous).  src_dev: [batch][H][W][3] float32.
+ * dst_dev: same shape, element type given by out_kind (float32 / uint16 / uint8).
+ * src_dev == dst_dev is allowed only for float32 outputs with usm_enabled == 0.
+ * Replaces, for one batch: ImageCorrectionWorker.run steps 5-7 (imageProcessorWorker.py:855-923),
+ * apply_all_adjustments (editingTools.py:823-909) and its callees. */
+int ss_chain_run(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev);
+
+/* Options of the host-buffer entry point. */
+typedef struct ss_host_opts {
+  /* neg_auto != 0 with desc->neg_enabled and desc->neg_params_dev == NULL: compute the percentiles on
+   * the device first (invert_negative_auto, editingTools.py:296-338) with these fractions; otherwise
+   * the descriptor's neg_p_low / neg_inv_denom are used. */
+  int32_t neg_auto;
+  int32_t legacy_numpy; /* see ss_percentile_rank */
+  double neg_low_percentile, neg_high_percentile;
+  /* lab_auto != 0: evaluate _is_lab_image (editingTools.py:411-432) on the uploaded data and, when it
+   * holds, run stages 4/5 on the LAB-in/LAB-out branch (as if desc->lab_io were set). */
+  int32_t lab_auto;
+  int32_t lab_detected; /* out: 1 when lab_auto found Lab data */
+} ss_host_opts;
+
+/* Same on host buffers (synchronous): pinned staging, async upload, kernels, async download.
+ * opts may be NULL (no automatic percentiles, no Lab detection). */
+int ss_chain_run_host(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_host, void* dst_host,
+                      ss_host_opts* opts);
+
+/* ---- negative film mode: per-channel percentiles ------------------------------------------ */
+
+/* Per-image detail of the percentile search (all exact order statistics of the strided sample). */
+typedef struct ss_percentile_detail {
+  float x_low_lo[3], x_low_hi[3];   /* order statistics bracketing the low percentile, per channel */
+  float x_high_lo[3], x_high_hi[3]; /* ... the high percentile */
+  double p_low[3], p_high[3];       /* interpolated percentiles (float64 lerp; float32 lerp if !legacy_numpy) */
+  int32_t step, n_samples;
+  int64_t k_low, k_high;            /* lower order-statistic index of each percentile */
+} ss_percentile_detail;
+
+/* Index arithmetic of np.percentile(method='linear') as called at editingTools.py:329-330 with
+ * `percentile * 100.0`: n samples, fraction in [0,1].  legacy_numpy != 0 -> numpy<2 (float64 index
+ * arithmetic, the reference's pin); 0 -> numpy>=2 (float32 arithmetic for float32 data).
+ * Pure host function. */
+int ss_percentile_rank(int64_t n, double fraction, int legacy_numpy, int64_t* lo, int64_t* hi, double* gamma);
+
+/* Sampling step of invert_negative_auto (editingTools.py:325). Pure host function. */
+int32_t ss_negative_sample_step(int32_t height, int32_t width);
+
+/* invert_negative_auto's statistics for a batch (editingTools.py:321-333): clip to [0,1], sample every
+ * `step`-th pixel in both directions, exact order statistics per channel via three 10-bit radix-select
+ * passes, linear interpolation, denom = max(p_high - p_low, 1e-3).
+ * params_dev: device [batch][SS_NEG_PARAM_STRIDE] floats (layout of ss_chain_desc::neg_params_dev).
+ * detail_dev: optional device [batch] ss_percentile_detail (may be NULL).  Asynchronous. */
+int ss_negative_params(ss_ctx* ctx, const float* src_dev, int32_t height, int32_t width, int32_t batch,
+                       double low_percentile, double high_percentile, int legacy_numpy,
+                       float* params_dev, ss_percentile_detail* detail_dev);
+
+/* ---- dataset exposure normalisation ------------------------------------------------------- */
+
+/* Per-thumbnail statistics of calculate_average_exposure (image_space.py:4360-4365):
+ * lum = 0.2126 R + 0.7152 G + 0.0722 B (float32), mask = (lum > shadow) & (lum < highlight),
+ * brightness = mean(lum[mask]) or mean(lum) when the mask is empty.
+ * thumbs_dev: [batch][h][w][3] float32.  stats_dev: optional device [batch][4] doubles
+ * {masked sum, masked count, total sum, total count}.  brightness_dev: device [batch] float32.
+ * Asynchronous. */
+int ss_exposure_stats(ss_ctx* ctx, const float* thumbs_dev, int32_t height, int32_t width, int32_t batch,
+                      float shadow_threshold, float highlight_threshold,
+                      double* stats_dev, float* brightness_dev);
+
+/* Multipliers of calculate_average_exposure (image_space.py:4376-4394) for n images whose
+ * brightness values are already gathered on this GPU: reference = brightness[ref_index], or the
+ * mean of all n when ref_index < 0; multiplier = reference / brightness (1.0 where brightness <= 0).
+ * Writes multipliers for images [first, first+count) to mult_dev[0..count).  Asynchronous. */
+int ss_exposure_multipliers(ss_ctx* ctx, const float* brightness_dev, int32_t n, int32_t ref_index,
+                            int32_t first, int32_t count, float* mult_dev);
+
+/* ---- LAB-input heuristic ------------------------------------------------------------------ */
+
+/* _is_lab_image (editingTools.py:411-432): max(ch0) > 1.5 and (min(ch1) < -1 or min(ch2) < -1).
+ * out_dev: device int32 (1 = looks like Lab).  minmax_dev: optional device float[3] = {max ch0, min ch1, min ch2}.
+ * Asynchronous. */
+int ss_is_lab_image(ss_ctx* ctx, const float* src_dev, int64_t n_pixels, int32_t* out_dev, float* minmax_dev);
+
+/* ---- plain device memory helpers for hosts without another HIP binding -------------------- */
+
+int ss_malloc(ss_ctx* ctx, uint64_t bytes, void** out_dev);
+int ss_free(ss_ctx* ctx, void* dev);
+/* Synchronous copies through the context's pinned staging ring. */
+int ss_upload(ss_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int ss_download(ss_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+
+/* ---- timing (HIP events on the context's stream) ------------------------------------------ */
+
+/* Record a start / stop event pair around whatever is queued in between and read the elapsed
+ * milliseconds after synchronising on the stop event. */
+int ss_timer_start(ss_ctx* ctx);
+int ss_timer_stop(ss_ctx* ctx, float* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANSPACE_H */

@@ -1,0 +1,243 @@
+"""Pixel operators of the correction chain, same names and signatures as the
+reference's ``ImageProcessor/editingTools.py``, executed by the gfx950 kernels of
+libscanspace_hip.so.
+
+Contract kept from the reference: numpy ``(H, W, 3)`` arrays in; a NEW array
+out (the input is never modified); every function returns its input object
+unchanged at its neutral setting.  Results are float32 (the reference returns
+float64 as soon as colour-science touches the data).
+
+Stages that run back to back (``apply_all_adjustments``) are fused into one
+kernel pass: one upload, one launch, one download.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib
+from ..chain import make_desc
+from .._lib import ScanSpaceError, default_context
+
+# np.percentile index arithmetic: True = numpy < 2 (the reference's pin, float64), False = numpy >= 2 (float32)
+NUMPY_LEGACY_PERCENTILE = True
+
+
+def _is_rgb_image(image) -> bool:
+    return image is not None and getattr(image, "ndim", 0) == 3 and image.shape[2] == 3
+
+
+def _run(image, *, lab_auto=False, **kw):
+    h, w, _ = image.shape
+    desc = make_desc(h, w, 1, **kw)
+    out, lab = default_context().chain_run_host(desc, image, lab_auto=lab_auto)
+    return out, lab
+
+
+# ---------------------------------------------------------------------------------------------
+# negative film (reference editingTools.py:296-365)
+# ---------------------------------------------------------------------------------------------
+
+
+def invert_negative_auto(image: np.ndarray, low_percentile: float = 0.05, high_percentile: float = 0.995) -> np.ndarray:
+    """Per-channel percentile normalisation and inversion (reference editingTools.py:296-338).
+    ``low_percentile=0.05`` is the 5th percentile.  Percentiles are exact order statistics of the
+    strided sample, found on the GPU."""
+    if not _is_rgb_image(image):
+        return image
+    h, w, _ = image.shape
+    desc = make_desc(h, w, 1, neg=True, out="f32")
+    out, _ = default_context().chain_run_host(desc, image, neg_auto=True, low=low_percentile, high=high_percentile,
+                                              legacy_numpy=NUMPY_LEGACY_PERCENTILE)
+    return out
+
+
+def ensure_positive_if_negative(image: np.ndarray, enabled: bool = False, low_percentile: float = 0.05,
+                                high_percentile: float = 0.995) -> np.ndarray:
+    """Reference editingTools.py:340-365: pass-through unless enabled; data errors fall back to the
+    original image.  A missing library or a failing GPU is NOT swallowed."""
+    if not enabled:
+        return image
+    try:
+        return invert_negative_auto(image, low_percentile, high_percentile)
+    except ScanSpaceError as e:
+        if e.code in (_lib.SS_ERR_HIP, _lib.SS_ERR_NOMEM):
+            raise
+        return image
+    except (ValueError, TypeError):
+        return image
+
+
+# ---------------------------------------------------------------------------------------------
+# Lab helpers (reference editingTools.py:411-432)
+# ---------------------------------------------------------------------------------------------
+
+
+def _is_lab_image(image: np.ndarray) -> bool:
+    """max(ch0) > 1.5 and (min(ch1) < -1 or min(ch2) < -1), reduced on the GPU."""
+    if image.shape[-1] != 3:
+        return False
+    ctx = default_context()
+    arr = np.ascontiguousarray(image, dtype=np.float32)
+    src = ctx.malloc(arr.nbytes)
+    flag = ctx.malloc(4)
+    try:
+        ctx.upload(src, arr)
+        ctx.is_lab_image(src, arr.size // 3, flag)
+        out = np.zeros(1, dtype=np.int32)
+        ctx.download(out, flag)
+        return bool(out[0])
+    finally:
+        ctx.free(src)
+        ctx.free(flag)
+
+
+# ---------------------------------------------------------------------------------------------
+# exposure / shadows / highlights / sharpen
+# ---------------------------------------------------------------------------------------------
+
+
+def adjust_exposure(image: np.ndarray, exposure_value: float) -> np.ndarray:
+    """``clip(image * 2**ev, 0, 1)`` (reference editingTools.py:435-466)."""
+    if exposure_value == 0:
+        return image
+    out, _ = _run(image, gains=[float(np.power(2.0, exposure_value))])
+    return out
+
+
+def adjust_shadows_highlights_combined(image: np.ndarray, shadow_amount: float, highlight_amount: float,
+                                       falloff_power: float = 7.0) -> np.ndarray:
+    """Exponential shadow/highlight curve on CIE L (reference editingTools.py:469-544)."""
+    if shadow_amount == 0 and highlight_amount == 0:
+        return image
+    out, _ = _run(image, lab_auto=True, sh=(shadow_amount, highlight_amount, falloff_power))
+    return out
+
+
+def adjust_sharpen(image: np.ndarray, amount: float = 0.0, radius: float = 1.0, threshold: float = 0.0) -> np.ndarray:
+    """Unsharp mask on CIE L with threshold and adaptive masks (reference editingTools.py:714-820)."""
+    if amount <= 0:
+        return image
+    out, _ = _run(image, lab_auto=True, usm=(amount, radius, threshold))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# white balance (reference editingTools.py:547-640)
+# ---------------------------------------------------------------------------------------------
+
+
+def _cct_to_xy_kang2002(cct: float):
+    """colour.temperature.CCT_to_xy default method (Kang et al. 2002), valid 1667 K .. 25000 K."""
+    T = float(cct)
+    if T <= 4000:
+        x = -0.2661239e9 / T ** 3 - 0.2343589e6 / T ** 2 + 0.8776956e3 / T + 0.179910
+    else:
+        x = -3.0258469e9 / T ** 3 + 2.1070379e6 / T ** 2 + 0.2226347e3 / T + 0.24039
+    if T <= 2222:
+        y = -1.1063814 * x ** 3 - 1.34811020 * x ** 2 + 2.18555832 * x - 0.20219683
+    elif T <= 4000:
+        y = -0.9549476 * x ** 3 - 1.37418593 * x ** 2 + 2.09137015 * x - 0.16748867
+    else:
+        y = 3.0817580 * x ** 3 - 5.8733867 * x ** 2 + 3.75112997 * x - 0.37001483
+    return x, y
+
+
+_M_XYZ_TO_SRGB = np.linalg.inv(np.array([[0.4124, 0.3576, 0.1805], [0.2126, 0.7152, 0.0722], [0.0193, 0.1192, 0.9505]]))
+
+
+def calculate_white_balance_multipliers(current_temp: float, target_temp: float, tint: float = 0.0):
+    """RGB multipliers from two colour temperatures (reference editingTools.py:547-602).  Host arithmetic."""
+
+    def rgb_of(cct):
+        x, y = _cct_to_xy_kang2002(cct)
+        XYZ = np.array([x / y, 1.0, (1.0 - x - y) / y])
+        return _M_XYZ_TO_SRGB @ XYZ
+
+    multipliers = rgb_of(target_temp) / (rgb_of(current_temp) + 1e-10)
+    if tint != 0:
+        multipliers[1] *= 1 + (tint / 100.0) * 0.1
+    min_mult = np.min(multipliers)
+    if min_mult > 0:
+        multipliers = multipliers / min_mult
+    return tuple(multipliers)
+
+
+def adjust_white_balance(image: np.ndarray, current_temp: float, target_temp: float, tint: float = 0.0) -> np.ndarray:
+    """Per-channel gains + clip (reference editingTools.py:605-640)."""
+    if current_temp == target_temp and tint == 0:
+        return image
+    out, _ = _run(image, gains=[calculate_white_balance_multipliers(current_temp, target_temp, tint)])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole adjustment chain (reference editingTools.py:823-909)
+# ---------------------------------------------------------------------------------------------
+
+
+def adjustment_stages(exposure=0.0, shadows=0.0, highlights=0.0, current_wb=5500.0, target_wb=5500.0, wb_tint=0.0,
+                      denoise_strength=0.0, sharpen_amount=0.0, sharpen_radius=1.0, sharpen_threshold=0.0):
+    """Translate apply_all_adjustments' arguments into chain stages (keyword arguments of make_desc).
+    Keeps the reference's pre-scaling ``shadows / 70`` and ``highlights * 1.3`` and its order
+    white balance -> exposure -> shadows/highlights -> sharpen."""
+    if denoise_strength > 0:
+        raise NotImplementedError("denoise (8-bit cv2 median/bilateral filters) is outside the accelerated chain")
+    shadows = shadows / 70
+    highlights = highlights * 1.3
+    kw = dict(gains=[])
+    if current_wb != target_wb or wb_tint != 0:
+        kw["gains"].append(calculate_white_balance_multipliers(current_wb, target_wb, wb_tint))
+    if exposure != 0:
+        kw["gains"].append(float(np.power(2.0, exposure)))
+    if shadows != 0 or highlights != 0:
+        kw["sh"] = (shadows, highlights, 7.0)
+    if sharpen_amount > 0:
+        kw["usm"] = (sharpen_amount, sharpen_radius, sharpen_threshold)
+    return kw
+
+
+def apply_all_adjustments(image: np.ndarray, exposure: float = 0.0, shadows: float = 0.0, highlights: float = 0.0,
+                          current_wb: float = 5500.0, target_wb: float = 5500.0, wb_tint: float = 0.0,
+                          denoise_strength: float = 0.0, sharpen_amount: float = 0.0, sharpen_radius: float = 1.0,
+                          sharpen_threshold: float = 0.0) -> np.ndarray:
+    """All adjustments in the reference's order, as ONE fused kernel pass."""
+    kw = adjustment_stages(exposure, shadows, highlights, current_wb, target_wb, wb_tint, denoise_strength,
+                           sharpen_amount, sharpen_radius, sharpen_threshold)
+    if not kw["gains"] and "sh" not in kw and "usm" not in kw:
+        return image.copy()
+    # the LAB-in heuristic is evaluated on what reaches the first Lab stage; after a gain+clip stage data is in [0,1]
+    lab_auto = not kw["gains"]
+    out, _ = _run(image, lab_auto=lab_auto, **kw)
+    return out
+
+
+class GlobalAdjustments:
+    """Parameter bag applied to the whole dataset (reference editingTools.py:913-976)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.exposure = 0.0
+        self.shadows = 0.0
+        self.highlights = 0.0
+        self.white_balance = None
+        self.wb_tint = 0.0
+        self.denoise_strength = 0.0
+        self.enabled = False
+
+    def has_adjustments(self) -> bool:
+        return self.enabled and (self.exposure != 0 or self.shadows != 0 or self.highlights != 0
+                                 or self.white_balance is not None or self.denoise_strength > 0)
+
+    def apply_to_image(self, image: np.ndarray, current_wb: float = 5500) -> np.ndarray:
+        if not self.enabled or not self.has_adjustments():
+            return image
+        target_wb = self.white_balance if self.white_balance else current_wb
+        return apply_all_adjustments(image, exposure=self.exposure, shadows=self.shadows, highlights=self.highlights,
+                                     current_wb=current_wb, target_wb=target_wb, wb_tint=self.wb_tint,
+                                     denoise_strength=self.denoise_strength)
+
+
+global_adjustments = GlobalAdjustments()

@@ -1,0 +1,261 @@
+"""ctypes binding of libscanspace_hip.so (declared in include/scanspace.h).
+
+The library is the only compute path of this package: if it is missing, or no
+gfx950 device is available when a context is requested, the call raises --
+there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscanspace_hip.so")
+
+SS_OK = 0
+SS_ERR_INVALID, SS_ERR_HIP, SS_ERR_NOMEM, SS_ERR_UNSUPPORTED = -1, -2, -3, -4
+
+SS_CCM_NONE, SS_CCM_CHEUNG, SS_CCM_ROOTPOLY = 0, 1, 2
+SS_OUT_F32_LINEAR, SS_OUT_F32_SRGB, SS_OUT_U16_SRGB, SS_OUT_U8_SRGB, SS_OUT_U8_LINEAR = 0, 1, 2, 3, 4
+SS_MAX_CCM_TERMS = 22
+SS_MAX_GAIN_STAGES = 3
+SS_MAX_USM_RADIUS = 15
+SS_NEG_PARAM_STRIDE = 8
+
+OUT_DTYPES = {
+    SS_OUT_F32_LINEAR: np.float32,
+    SS_OUT_F32_SRGB: np.float32,
+    SS_OUT_U16_SRGB: np.uint16,
+    SS_OUT_U8_SRGB: np.uint8,
+    SS_OUT_U8_LINEAR: np.uint8,
+}
+
+
+class ChainDesc(C.Structure):
+    """Mirror of ``ss_chain_desc``."""
+
+    _fields_ = [
+        ("height", C.c_int32), ("width", C.c_int32), ("batch", C.c_int32),
+        ("neg_enabled", C.c_int32),
+        ("neg_p_low", C.c_float * 3),
+        ("neg_inv_denom", C.c_float * 3),
+        ("neg_params_dev", C.c_void_p),
+        ("ccm_kind", C.c_int32), ("ccm_terms", C.c_int32),
+        ("ccm", C.c_float * (3 * SS_MAX_CCM_TERMS)),
+        ("n_gain_stages", C.c_int32),
+        ("gain", (C.c_float * 3) * SS_MAX_GAIN_STAGES),
+        ("gain0_dev", C.c_void_p),
+        ("sh_enabled", C.c_int32),
+        ("sh_shadow_amount", C.c_float), ("sh_highlight_amount", C.c_float), ("sh_falloff_power", C.c_float),
+        ("usm_enabled", C.c_int32),
+        ("usm_amount", C.c_float), ("usm_radius", C.c_float), ("usm_threshold", C.c_float),
+        ("lab_io", C.c_int32),
+        ("final_clip", C.c_int32),
+        ("out_kind", C.c_int32),
+    ]
+
+
+class HostOpts(C.Structure):
+    """Mirror of ``ss_host_opts``."""
+
+    _fields_ = [
+        ("neg_auto", C.c_int32), ("legacy_numpy", C.c_int32),
+        ("neg_low_percentile", C.c_double), ("neg_high_percentile", C.c_double),
+        ("lab_auto", C.c_int32), ("lab_detected", C.c_int32),
+    ]
+
+
+class PercentileDetail(C.Structure):
+    """Mirror of ``ss_percentile_detail``."""
+
+    _fields_ = [
+        ("x_low_lo", C.c_float * 3), ("x_low_hi", C.c_float * 3),
+        ("x_high_lo", C.c_float * 3), ("x_high_hi", C.c_float * 3),
+        ("p_low", C.c_double * 3), ("p_high", C.c_double * 3),
+        ("step", C.c_int32), ("n_samples", C.c_int32),
+        ("k_low", C.c_int64), ("k_high", C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/scanspace.h declares
+SIGNATURES = {
+    "ss_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ss_ctx_destroy": (None, [C.c_void_p]),
+    "ss_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_ctx_sync": (C.c_int, [C.c_void_p]),
+    "ss_last_error": (C.c_char_p, [C.c_void_p]),
+    "ss_version": (C.c_char_p, []),
+    "ss_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
+    "ss_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p, C.POINTER(HostOpts)]),
+    "ss_percentile_rank": (C.c_int, [C.c_int64, C.c_double, C.c_int, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "ss_negative_sample_step": (C.c_int32, [C.c_int32, C.c_int32]),
+    "ss_negative_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "ss_exposure_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "ss_exposure_multipliers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_void_p]),
+    "ss_is_lab_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ss_malloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ss_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ss_timer_start": (C.c_int, [C.c_void_p]),
+    "ss_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class ScanSpaceError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libscanspace_hip error {code}: {message}")
+        self.code = code
+
+
+def load_library():
+    """Load libscanspace_hip.so (built in-tree by ``__graft_entry__.build()``) and type its symbols."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+class Context:
+    """One ``ss_ctx``: a GPU, a stream, workspace and pinned staging.  Not thread-safe; use
+    ``default_context()`` for a per-thread instance."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.ss_ctx_create(int(device), C.byref(h))
+        if rc != SS_OK:
+            raise ScanSpaceError(rc, self.lib.ss_last_error(None).decode())
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ss_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != SS_OK:
+            raise ScanSpaceError(rc, self.lib.ss_last_error(self.handle).decode())
+
+    # -- streams / sync / timing
+    def set_stream(self, hip_stream):
+        self.check(self.lib.ss_ctx_set_stream(self.handle, C.c_void_p(hip_stream or None)))
+
+    def sync(self):
+        self.check(self.lib.ss_ctx_sync(self.handle))
+
+    def timer_start(self):
+        self.check(self.lib.ss_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.check(self.lib.ss_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # -- memory
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.ss_malloc(self.handle, int(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        self.check(self.lib.ss_free(self.handle, C.c_void_p(ptr)))
+
+    def upload(self, dst_dev, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.ss_upload(self.handle, C.c_void_p(dst_dev), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def download(self, arr, src_dev):
+        assert arr.flags.c_contiguous and arr.flags.writeable
+        self.check(self.lib.ss_download(self.handle, arr.ctypes.data_as(C.c_void_p), C.c_void_p(src_dev), arr.nbytes))
+
+    # -- entry points on device pointers
+    def chain_run(self, desc, src_dev, dst_dev):
+        self.check(self.lib.ss_chain_run(self.handle, C.byref(desc), C.c_void_p(src_dev), C.c_void_p(dst_dev)))
+
+    def negative_params(self, src_dev, height, width, batch, low, high, legacy_numpy, params_dev, detail_dev=None):
+        self.check(self.lib.ss_negative_params(self.handle, C.c_void_p(src_dev), height, width, batch,
+                                               float(low), float(high), int(bool(legacy_numpy)),
+                                               C.c_void_p(params_dev), C.c_void_p(detail_dev or None)))
+
+    def exposure_stats(self, thumbs_dev, height, width, batch, shadow, highlight, stats_dev, brightness_dev):
+        self.check(self.lib.ss_exposure_stats(self.handle, C.c_void_p(thumbs_dev), height, width, batch,
+                                              float(shadow), float(highlight),
+                                              C.c_void_p(stats_dev or None), C.c_void_p(brightness_dev)))
+
+    def exposure_multipliers(self, brightness_dev, n, ref_index, first, count, mult_dev):
+        self.check(self.lib.ss_exposure_multipliers(self.handle, C.c_void_p(brightness_dev), n,
+                                                    -1 if ref_index is None else int(ref_index),
+                                                    first, count, C.c_void_p(mult_dev)))
+
+    def is_lab_image(self, src_dev, n_pixels, out_dev, minmax_dev=None):
+        self.check(self.lib.ss_is_lab_image(self.handle, C.c_void_p(src_dev), int(n_pixels),
+                                            C.c_void_p(out_dev), C.c_void_p(minmax_dev or None)))
+
+    # -- entry point on host arrays
+    def chain_run_host(self, desc, src, neg_auto=False, low=0.05, high=0.995, legacy_numpy=True, lab_auto=False):
+        """Run the chain on a C-contiguous float32 array of shape (H, W, 3) or (B, H, W, 3).
+        Returns ``(out, lab_detected)``."""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        out = np.empty(src.shape, dtype=OUT_DTYPES[desc.out_kind])
+        opts = HostOpts(int(bool(neg_auto)), int(bool(legacy_numpy)), float(low), float(high), int(bool(lab_auto)), 0)
+        self.check(self.lib.ss_chain_run_host(self.handle, C.byref(desc), src.ctypes.data_as(C.c_void_p),
+                                              out.ctypes.data_as(C.c_void_p), C.byref(opts)))
+        return out, bool(opts.lab_detected)
+
+
+_tls = threading.local()
+
+
+def default_context(device=None):
+    """Per-thread context (the reference runs several worker threads at once)."""
+    if device is None:
+        device = int(os.environ.get("SCANSPACE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctxs = getattr(_tls, "ctxs", None)
+    if ctxs is None:
+        ctxs = _tls.ctxs = {}
+    if device not in ctxs:
+        ctxs[device] = Context(device)
+    return ctxs[device]
+
+
+def percentile_rank(n, fraction, legacy_numpy=True):
+    """Host-only: order-statistic indices and weight of np.percentile(method='linear')."""
+    lib = load_library()
+    lo, hi, g = C.c_int64(), C.c_int64(), C.c_double()
+    rc = lib.ss_percentile_rank(int(n), float(fraction), int(bool(legacy_numpy)), C.byref(lo), C.byref(hi), C.byref(g))
+    if rc != SS_OK:
+        raise ScanSpaceError(rc, "invalid percentile arguments")
+    return lo.value, hi.value, g.value
+
+
+def negative_sample_step(height, width):
+    return int(load_library().ss_negative_sample_step(int(height), int(width)))

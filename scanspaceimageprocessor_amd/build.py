@@ -1,0 +1,70 @@
+"""In-tree build of libscanspace_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libscanspace_hip.so")
+SOURCES = ["chain.hip", "usm.hip", "stats.hip", "api.hip"]
+HEADERS = ["ss_device.h", "ss_internal.h", os.path.join("..", "..", "include", "scanspace.h")]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; ROCm is required to build libscanspace_hip.so")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source to an object (in parallel) and link the shared library."""
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{r.stderr}")
+        if verbose and r.stderr:
+            print(r.stderr)
+        return o
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(compile_one, jobs))
+    objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB, *objs],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,562 @@
+// C ABI of libscanspace_hip.so (declared in include/scanspace.h): context management, descriptor
+// validation, host-side parameter derivation, workspace and pinned staging.
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "ss_internal.h"
+
+using namespace ss;
+
+namespace {
+
+constexpr size_t kStageBytes = 32u << 20;  // each of the two pinned staging buffers
+constexpr int64_t kMaxPixels = (int64_t)1 << 28;  // 32-bit element offsets inside one image
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct ss_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // lazily grown device workspace
+  void* ws_samples = nullptr;
+  size_t ws_samples_bytes = 0;
+  void* ws_small = nullptr;  // histograms, select state, partials
+  size_t ws_small_bytes = 0;
+  // host path
+  void* pinned[2] = {nullptr, nullptr};
+  hipEvent_t pinned_free[2] = {nullptr, nullptr};
+  void* host_src = nullptr;
+  void* host_dst = nullptr;
+  void* host_neg = nullptr;
+  size_t host_src_bytes = 0, host_dst_bytes = 0;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace {
+
+int fail(ss_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define SS_HIP(c, call)                                                                             \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail((c), e_ == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "%s failed: %s", #call, \
+                  hipGetErrorString(e_));                                                           \
+  } while (0)
+
+int grow(ss_ctx* c, void** p, size_t* have, size_t need) {
+  if (*have >= need) return SS_OK;
+  if (*p) {
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    SS_HIP(c, hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  SS_HIP(c, hipMalloc(p, need));
+  *have = need;
+  return SS_OK;
+}
+
+void invert3x3(const double m[9], double inv[9]) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  inv[0] = (e * i - f * h) / det;
+  inv[1] = (c * h - b * i) / det;
+  inv[2] = (b * f - c * e) / det;
+  inv[3] = (f * g - d * i) / det;
+  inv[4] = (a * i - c * g) / det;
+  inv[5] = (c * d - a * f) / det;
+  inv[6] = (d * h - e * g) / det;
+  inv[7] = (b * g - a * h) / det;
+  inv[8] = (a * e - b * d) / det;
+}
+
+bool cheung_terms_ok(int t) {
+  switch (t) {
+    case 3: case 5: case 7: case 8: case 10: case 11: case 14: case 16: case 17: case 19: case 20: case 22:
+      return true;
+    default:
+      return false;
+  }
+}
+bool rootpoly_terms_ok(int t) { return t == 3 || t == 6 || t == 13 || t == 22; }
+
+int usm_kernel_size(double sigma) {
+  int k = (int)(6 * sigma) + 1;  // editingTools.py:756-758
+  if (k % 2 == 0) k += 1;
+  return k;
+}
+
+// Validate a descriptor and derive the kernel parameters from it.
+int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
+  if (!d) return fail(c, SS_ERR_INVALID, "descriptor is NULL");
+  if (d->height <= 0 || d->width <= 0 || d->batch <= 0)
+    return fail(c, SS_ERR_INVALID, "height, width and batch must be positive (got %d x %d x %d)", d->height, d->width,
+                d->batch);
+  if ((int64_t)d->height * d->width > kMaxPixels)
+    return fail(c, SS_ERR_UNSUPPORTED, "image of %lld pixels exceeds the %lld-pixel limit per image",
+                (long long)d->height * d->width, (long long)kMaxPixels);
+  if (d->batch > 65535) return fail(c, SS_ERR_UNSUPPORTED, "batch %d exceeds 65535 images per call", d->batch);
+  memset(P, 0, sizeof *P);
+  P->height = d->height;
+  P->width = d->width;
+  P->n_px = (int64_t)d->height * d->width;
+
+  P->neg = d->neg_enabled ? 1 : 0;
+  if (P->neg) {
+    P->neg_dev = d->neg_params_dev;
+    for (int k = 0; k < 3; ++k) {
+      P->neg_lo[k] = d->neg_p_low[k];
+      P->neg_inv[k] = d->neg_inv_denom[k];
+    }
+  }
+
+  P->ccm_kind = d->ccm_kind;
+  P->ccm_terms = d->ccm_terms;
+  if (d->ccm_kind == SS_CCM_CHEUNG) {
+    if (!cheung_terms_ok(d->ccm_terms))
+      return fail(c, SS_ERR_INVALID, "\"Cheung 2004\" defines no augmented matrix with %d terms", d->ccm_terms);
+  } else if (d->ccm_kind == SS_CCM_ROOTPOLY) {
+    if (!rootpoly_terms_ok(d->ccm_terms))
+      return fail(c, SS_ERR_INVALID, "\"Finlayson 2015\" root-polynomial expansion has 3, 6, 13 or 22 terms, not %d",
+                  d->ccm_terms);
+  } else if (d->ccm_kind != SS_CCM_NONE) {
+    return fail(c, SS_ERR_INVALID, "unknown ccm_kind %d", d->ccm_kind);
+  }
+  if (d->ccm_kind != SS_CCM_NONE) memcpy(P->ccm, d->ccm, sizeof(float) * 3 * d->ccm_terms);
+
+  if (d->n_gain_stages < 0 || d->n_gain_stages > SS_MAX_GAIN_STAGES)
+    return fail(c, SS_ERR_INVALID, "n_gain_stages must be 0..%d", SS_MAX_GAIN_STAGES);
+  if (d->gain0_dev && d->n_gain_stages < 1)
+    return fail(c, SS_ERR_INVALID, "gain0_dev needs at least one gain stage");
+  P->n_gain = d->n_gain_stages;
+  memcpy(P->gain, d->gain, sizeof P->gain);
+  P->gain0_dev = d->gain0_dev;
+
+  P->sh = (d->sh_enabled && (d->sh_shadow_amount != 0.0f || d->sh_highlight_amount != 0.0f)) ? 1 : 0;
+  if (P->sh) {
+    if (!(d->sh_falloff_power > 0.0f)) return fail(c, SS_ERR_INVALID, "sh_falloff_power must be positive");
+    P->sh_ss = (float)((double)d->sh_shadow_amount * 0.05);
+    P->sh_hs = (float)((double)d->sh_highlight_amount * 0.05);
+    P->sh_log2f = (float)log2((double)d->sh_falloff_power);
+    P->sh_chroma = (fabsf(d->sh_shadow_amount) > 50.0f || fabsf(d->sh_highlight_amount) > 50.0f) ? 1 : 0;
+  }
+
+  P->usm = (d->usm_enabled && d->usm_amount > 0.0f) ? 1 : 0;
+  if (P->usm) {
+    if (!(d->usm_radius > 0.0f)) return fail(c, SS_ERR_INVALID, "usm_radius (sigma) must be positive");
+    const int k = usm_kernel_size(d->usm_radius);
+    const int r = k / 2;
+    if (r < 1 || r > SS_MAX_USM_RADIUS)
+      return fail(c, SS_ERR_UNSUPPORTED, "usm_radius %.3f needs a %d-tap kernel; supported sizes are 3..%d taps",
+                  d->usm_radius, k, 2 * SS_MAX_USM_RADIUS + 1);
+    P->usm_r = r;
+    // cv2.getGaussianKernel: taps in double, normalised, rounded to float32
+    double g[2 * SS_MAX_USM_RADIUS + 1], sum = 0.0;
+    const double s = (double)d->usm_radius;
+    for (int i = 0; i < k; ++i) {
+      const double x = i - (k - 1) * 0.5;
+      g[i] = exp(-(x * x) / (2.0 * s * s));
+      sum += g[i];
+    }
+    for (int i = 0; i < k; ++i) P->taps[i] = (float)(g[i] / sum);
+    P->usm_amount_scaled = (float)((double)d->usm_amount / 50.0);
+    P->usm_thr = (float)((double)d->usm_threshold / 100.0);
+    P->usm_inv_thr = P->usm_thr > 0.0f ? (float)(100.0 / (double)d->usm_threshold) : 0.0f;
+    P->usm_chroma = d->usm_amount > 30.0f ? 1 : 0;
+    P->usm_chroma_k = (float)((double)d->usm_amount / 100.0 * 0.1);
+  }
+
+  P->lab_io = d->lab_io ? 1 : 0;
+  if (P->lab_io) {
+    if (P->neg || P->ccm_kind != SS_CCM_NONE || P->n_gain || d->final_clip || d->out_kind != SS_OUT_F32_LINEAR)
+      return fail(c, SS_ERR_INVALID,
+                  "lab_io requires no inversion, no colour correction, no gain stages, no final clip and F32_LINEAR output");
+  }
+  P->final_clip = d->final_clip ? 1 : 0;
+  if (d->out_kind < SS_OUT_F32_LINEAR || d->out_kind > SS_OUT_U8_LINEAR)
+    return fail(c, SS_ERR_INVALID, "unknown out_kind %d", d->out_kind);
+
+  // sRGB <-> XYZ (colour's sRGB colourspace: the published 4-digit matrix and its numerical inverse)
+  // folded with the D65 white of XYZ_to_Lab / Lab_to_XYZ: xy = (0.3127, 0.3290)
+  const double M[9] = {0.4124, 0.3576, 0.1805, 0.2126, 0.7152, 0.0722, 0.0193, 0.1192, 0.9505};
+  double Minv[9];
+  invert3x3(M, Minv);
+  const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 3; ++k) {
+      P->m_fwd[r * 3 + k] = (float)(M[r * 3 + k] / white[r]);
+      P->m_inv[r * 3 + k] = (float)(Minv[r * 3 + k] * white[k]);
+    }
+  return SS_OK;
+}
+
+size_t out_bytes_per_px(int out_kind) {
+  return out_kind == SS_OUT_U16_SRGB ? 6 : (out_kind == SS_OUT_U8_SRGB || out_kind == SS_OUT_U8_LINEAR) ? 3 : 12;
+}
+
+int ensure_pinned(ss_ctx* c) {
+  for (int i = 0; i < 2; ++i) {
+    if (!c->pinned[i]) {
+      SS_HIP(c, hipHostMalloc(&c->pinned[i], kStageBytes, hipHostMallocDefault));
+      SS_HIP(c, hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming));
+    }
+  }
+  return SS_OK;
+}
+
+int copy_h2d(ss_ctx* c, void* dst, const void* src, size_t bytes) {
+  int rc = ensure_pinned(c);
+  if (rc) return rc;
+  size_t off = 0;
+  int b = 0;
+  while (off < bytes) {
+    const size_t n = bytes - off < kStageBytes ? bytes - off : kStageBytes;
+    SS_HIP(c, hipEventSynchronize(c->pinned_free[b]));
+    memcpy(c->pinned[b], (const char*)src + off, n);
+    SS_HIP(c, hipMemcpyAsync((char*)dst + off, c->pinned[b], n, hipMemcpyHostToDevice, c->stream));
+    SS_HIP(c, hipEventRecord(c->pinned_free[b], c->stream));
+    off += n;
+    b ^= 1;
+  }
+  return SS_OK;
+}
+
+int copy_d2h(ss_ctx* c, void* dst, const void* src, size_t bytes) {
+  int rc = ensure_pinned(c);
+  if (rc) return rc;
+  // two-deep pipeline: the copy into one staging buffer overlaps the memcpy out of the other
+  size_t off_issue = 0, off_done = 0;
+  size_t len[2] = {0, 0};
+  int bi = 0, bd = 0;
+  while (off_done < bytes) {
+    while (off_issue < bytes && off_issue - off_done < 2 * kStageBytes && len[bi] == 0) {
+      const size_t n = bytes - off_issue < kStageBytes ? bytes - off_issue : kStageBytes;
+      SS_HIP(c, hipMemcpyAsync(c->pinned[bi], (const char*)src + off_issue, n, hipMemcpyDeviceToHost, c->stream));
+      SS_HIP(c, hipEventRecord(c->pinned_free[bi], c->stream));
+      len[bi] = n;
+      off_issue += n;
+      bi ^= 1;
+    }
+    SS_HIP(c, hipEventSynchronize(c->pinned_free[bd]));
+    memcpy((char*)dst + off_done, c->pinned[bd], len[bd]);
+    off_done += len[bd];
+    len[bd] = 0;
+    bd ^= 1;
+  }
+  return SS_OK;
+}
+
+int check_ctx(ss_ctx* c) {
+  if (!c) return fail(nullptr, SS_ERR_INVALID, "context is NULL");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(e));
+  return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ss_version(void) { return "scanspace-hip 0.1 (gfx950)"; }
+
+int ss_ctx_create(int device, ss_ctx** out_ctx) {
+  if (!out_ctx) return fail(nullptr, SS_ERR_INVALID, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, SS_ERR_HIP, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= count) return fail(nullptr, SS_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, SS_ERR_HIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(nullptr, SS_ERR_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, SS_ERR_UNSUPPORTED, "device %d is %s; this library only carries gfx950 code", device,
+                prop.gcnArchName);
+  ss_ctx* c = new ss_ctx();
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(nullptr, SS_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  hipEventCreate(&c->t0);
+  hipEventCreate(&c->t1);
+  *out_ctx = c;
+  return SS_OK;
+}
+
+void ss_ctx_destroy(ss_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->ws_samples) hipFree(c->ws_samples);
+  if (c->ws_small) hipFree(c->ws_small);
+  if (c->host_src) hipFree(c->host_src);
+  if (c->host_dst) hipFree(c->host_dst);
+  if (c->host_neg) hipFree(c->host_neg);
+  for (int i = 0; i < 2; ++i) {
+    if (c->pinned[i]) hipHostFree(c->pinned[i]);
+    if (c->pinned_free[i]) hipEventDestroy(c->pinned_free[i]);
+  }
+  if (c->t0) hipEventDestroy(c->t0);
+  if (c->t1) hipEventDestroy(c->t1);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int ss_ctx_set_stream(ss_ctx* c, void* hip_stream) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return SS_OK;
+}
+
+int ss_ctx_sync(ss_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  return SS_OK;
+}
+
+const char* ss_last_error(const ss_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!src_dev || !dst_dev) return fail(c, SS_ERR_INVALID, "src_dev and dst_dev must not be NULL");
+  ChainParams P;
+  rc = build_params(c, d, &P);
+  if (rc) return rc;
+  if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
+    return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
+  hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream)
+                       : launch_chain(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_percentile_rank(int64_t n, double fraction, int legacy_numpy, int64_t* lo, int64_t* hi, double* gamma) {
+  if (n <= 0 || !lo || !hi || !gamma || !(fraction >= 0.0 && fraction <= 1.0)) return SS_ERR_INVALID;
+  // editingTools.py:329 passes `fraction * 100.0`; np.percentile divides by 100 again
+  // (in float32 for float32 data under numpy >= 2), then index = (n - 1) * q
+  double v;
+  if (legacy_numpy) {
+    const double q = (fraction * 100.0) / 100.0;
+    v = (double)(n - 1) * q;
+  } else {
+    // np.true_divide(python_float, np.float32(100)) -> float32; (n-1) * q -> float32
+    const float q = (float)(fraction * 100.0) / 100.0f;
+    v = (double)((float)(n - 1) * q);
+  }
+  if (v >= (double)(n - 1)) {
+    *lo = *hi = n - 1;
+    *gamma = 0.0;
+  } else if (v < 0.0) {
+    *lo = *hi = 0;
+    *gamma = 0.0;
+  } else {
+    const double f = floor(v);
+    *lo = (int64_t)f;
+    *hi = *lo + 1;
+    *gamma = v - f;
+  }
+  return SS_OK;
+}
+
+int32_t ss_negative_sample_step(int32_t height, int32_t width) {
+  const int s = (int)sqrt(((double)height * (double)width) / 250000.0);  // editingTools.py:325
+  return s < 1 ? 1 : s;
+}
+
+int ss_negative_params(ss_ctx* c, const float* src_dev, int32_t height, int32_t width, int32_t batch,
+                       double low_percentile, double high_percentile, int legacy_numpy, float* params_dev,
+                       ss_percentile_detail* detail_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!src_dev || !params_dev) return fail(c, SS_ERR_INVALID, "src_dev and params_dev must not be NULL");
+  if (height <= 0 || width <= 0 || batch <= 0 || batch > 65535)
+    return fail(c, SS_ERR_INVALID, "bad geometry %d x %d x %d", height, width, batch);
+  if ((int64_t)height * width > kMaxPixels) return fail(c, SS_ERR_UNSUPPORTED, "image too large");
+  const int step = ss_negative_sample_step(height, width);
+  const int64_t hs = (height + step - 1) / step, ws = (width + step - 1) / step;
+  const int64_t n = hs * ws;
+  int64_t kl, klh, kh, khh;
+  double gl, gh;
+  if (ss_percentile_rank(n, low_percentile, legacy_numpy, &kl, &klh, &gl) ||
+      ss_percentile_rank(n, high_percentile, legacy_numpy, &kh, &khh, &gh))
+    return fail(c, SS_ERR_INVALID, "percentile fractions must lie in [0,1] (got %g, %g)", low_percentile,
+                high_percentile);
+  rc = grow(c, &c->ws_samples, &c->ws_samples_bytes, percentile_samples_bytes(batch, n));
+  if (rc) return rc;
+  const size_t hist_b = percentile_hist_bytes(batch), state_b = percentile_state_bytes(batch);
+  rc = grow(c, &c->ws_small, &c->ws_small_bytes, hist_b + state_b);
+  if (rc) return rc;
+  PercentileWork w;
+  w.samples = (uint32_t*)c->ws_samples;
+  w.hist = (uint32_t*)c->ws_small;
+  w.state = (uint32_t*)((char*)c->ws_small + hist_b);
+  hipError_t e = launch_negative_params(src_dev, height, width, batch, step, n, kl, klh, gl, kh, khh, gh,
+                                        legacy_numpy ? 1 : 0, w, params_dev, detail_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "percentile kernels failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_exposure_stats(ss_ctx* c, const float* thumbs_dev, int32_t height, int32_t width, int32_t batch,
+                      float shadow_threshold, float highlight_threshold, double* stats_dev, float* brightness_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!thumbs_dev || !brightness_dev) return fail(c, SS_ERR_INVALID, "thumbs_dev and brightness_dev must not be NULL");
+  if (height <= 0 || width <= 0 || batch <= 0 || batch > 65535 || (int64_t)height * width > kMaxPixels)
+    return fail(c, SS_ERR_INVALID, "bad geometry %d x %d x %d", height, width, batch);
+  rc = grow(c, &c->ws_small, &c->ws_small_bytes, (size_t)batch * kStatsBlocksPerImage * 4 * sizeof(double));
+  if (rc) return rc;
+  hipError_t e = launch_exposure_stats(thumbs_dev, height, width, batch, shadow_threshold, highlight_threshold,
+                                       (double*)c->ws_small, stats_dev, brightness_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "exposure kernels failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_exposure_multipliers(ss_ctx* c, const float* brightness_dev, int32_t n, int32_t ref_index, int32_t first,
+                            int32_t count, float* mult_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!brightness_dev || !mult_dev) return fail(c, SS_ERR_INVALID, "brightness_dev and mult_dev must not be NULL");
+  if (n <= 0 || ref_index >= n || first < 0 || count < 0 || first + count > n)
+    return fail(c, SS_ERR_INVALID, "bad range: n=%d ref_index=%d first=%d count=%d", n, ref_index, first, count);
+  hipError_t e = launch_exposure_multipliers(brightness_dev, n, ref_index, first, count, mult_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "multiplier kernel failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_is_lab_image(ss_ctx* c, const float* src_dev, int64_t n_pixels, int32_t* out_dev, float* minmax_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!src_dev || !out_dev || n_pixels <= 0) return fail(c, SS_ERR_INVALID, "bad arguments");
+  rc = grow(c, &c->ws_small, &c->ws_small_bytes, (size_t)kLabDetectBlocks * 3 * sizeof(float));
+  if (rc) return rc;
+  hipError_t e = launch_is_lab(src_dev, n_pixels, (float*)c->ws_small, out_dev, minmax_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "lab-detect kernels failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_malloc(ss_ctx* c, uint64_t bytes, void** out_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!out_dev || bytes == 0) return fail(c, SS_ERR_INVALID, "bad arguments");
+  SS_HIP(c, hipMalloc(out_dev, bytes));
+  return SS_OK;
+}
+
+int ss_free(ss_ctx* c, void* dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (dev) {
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    SS_HIP(c, hipFree(dev));
+  }
+  return SS_OK;
+}
+
+int ss_upload(ss_ctx* c, void* dst_dev, const void* src_host, uint64_t bytes) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!dst_dev || !src_host) return fail(c, SS_ERR_INVALID, "NULL pointer");
+  rc = copy_h2d(c, dst_dev, src_host, bytes);
+  if (rc) return rc;
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  return SS_OK;
+}
+
+int ss_download(ss_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!dst_host || !src_dev) return fail(c, SS_ERR_INVALID, "NULL pointer");
+  return copy_d2h(c, dst_host, src_dev, bytes);
+}
+
+int ss_chain_run_host(ss_ctx* c, const ss_chain_desc* d, const float* src_host, void* dst_host, ss_host_opts* opts) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d || !src_host || !dst_host) return fail(c, SS_ERR_INVALID, "NULL argument");
+  ChainParams P;
+  rc = build_params(c, d, &P);  // validate before moving any data
+  if (rc) return rc;
+  const size_t n_px = (size_t)d->height * d->width * d->batch;
+  const size_t in_bytes = n_px * 12, out_bytes = n_px * out_bytes_per_px(d->out_kind);
+  rc = grow(c, &c->host_src, &c->host_src_bytes, in_bytes);
+  if (rc) return rc;
+  rc = grow(c, &c->host_dst, &c->host_dst_bytes, out_bytes);
+  if (rc) return rc;
+  rc = copy_h2d(c, c->host_src, src_host, in_bytes);
+  if (rc) return rc;
+  ss_chain_desc dd = *d;
+  if (!c->host_neg) SS_HIP(c, hipMalloc(&c->host_neg, 65536 * SS_NEG_PARAM_STRIDE * sizeof(float)));
+  if (opts && opts->neg_auto && d->neg_enabled && !d->neg_params_dev) {
+    rc = ss_negative_params(c, (const float*)c->host_src, d->height, d->width, d->batch, opts->neg_low_percentile,
+                            opts->neg_high_percentile, opts->legacy_numpy, (float*)c->host_neg, nullptr);
+    if (rc) return rc;
+    dd.neg_params_dev = (const float*)c->host_neg;
+  }
+  if (opts) opts->lab_detected = 0;
+  if (opts && opts->lab_auto && !d->lab_io) {
+    // the flag word lives behind the (unused here) tail of the negative-parameter table
+    int32_t* flag_dev = (int32_t*)((char*)c->host_neg + 65535 * SS_NEG_PARAM_STRIDE * sizeof(float));
+    rc = ss_is_lab_image(c, (const float*)c->host_src, (int64_t)n_px, flag_dev, nullptr);
+    if (rc) return rc;
+    int32_t flag = 0;
+    SS_HIP(c, hipMemcpyAsync(&flag, flag_dev, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    if (flag) {
+      opts->lab_detected = 1;
+      dd.lab_io = 1;
+    }
+  }
+  rc = ss_chain_run(c, &dd, (const float*)c->host_src, c->host_dst);
+  if (rc) return rc;
+  return copy_d2h(c, dst_host, c->host_dst, out_bytes);
+}
+
+int ss_timer_start(ss_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  SS_HIP(c, hipEventRecord(c->t0, c->stream));
+  return SS_OK;
+}
+
+int ss_timer_stop(ss_ctx* c, float* elapsed_ms) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!elapsed_ms) return fail(c, SS_ERR_INVALID, "elapsed_ms is NULL");
+  SS_HIP(c, hipEventRecord(c->t1, c->stream));
+  SS_HIP(c, hipEventSynchronize(c->t1));
+  SS_HIP(c, hipEventElapsedTime(elapsed_ms, c->t0, c->t1));
+  return SS_OK;
+}
+
+}  // extern "C"

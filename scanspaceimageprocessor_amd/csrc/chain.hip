@@ -1,0 +1,141 @@
+// Pointwise fused correction-chain kernel for gfx950.
+//
+//   chain_kernel : stages 1-4, 6, 7 as one pointwise pass.  One lane owns G adjacent pixels so
+//                  that every lane stores exactly 12 bytes (one global_store_dwordx3, lanes
+//                  contiguous): G = 1 for float32, 2 for uint16, 4 for uint8 output.  Loads are
+//                  per-pixel global_load_dwordx3 (12 B, 4-byte aligned, no width restriction).
+//                  Algorithmic traffic: 12 B/px in + 12 / 6 / 3 B/px out; HBM-bound.
+
+#include "ss_internal.h"
+
+namespace ss {
+
+// ------------------------------------------------------------------------------------------------
+// pointwise chain
+// ------------------------------------------------------------------------------------------------
+
+template <int OUT>
+__device__ __forceinline__ void store_one(void* dst_img, uint32_t px, const Px p) {
+  if constexpr (OUT == SS_OUT_F32_LINEAR || OUT == SS_OUT_F32_SRGB) {
+    reinterpret_cast<F3*>(dst_img)[px] = F3{p.r, p.g, p.b};
+  } else if constexpr (OUT == SS_OUT_U16_SRGB) {
+    uint16_t* d = reinterpret_cast<uint16_t*>(dst_img) + (size_t)px * 3;
+    d[0] = (uint16_t)quant16(p.r);
+    d[1] = (uint16_t)quant16(p.g);
+    d[2] = (uint16_t)quant16(p.b);
+  } else {
+    uint8_t* d = reinterpret_cast<uint8_t*>(dst_img) + (size_t)px * 3;
+    d[0] = (uint8_t)quant8(p.r);
+    d[1] = (uint8_t)quant8(p.g);
+    d[2] = (uint8_t)quant8(p.b);
+  }
+}
+
+template <int CCMC, bool SH, int OUT>
+__global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const float* __restrict__ src,
+                                                    void* __restrict__ dst) {
+  constexpr int G = OutTraits<OUT>::G;
+  constexpr int K = 4 / G;  // groups per lane per trip: 4 pixels in flight per lane
+  const int img = blockIdx.y;
+  const ImgParams ip = load_img_params(P, img);
+  const uint32_t n = (uint32_t)P.n_px;
+  const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * n * 3);
+  char* d = reinterpret_cast<char*>(dst) + (size_t)img * n * 3 * OutTraits<OUT>::BYTES;
+  const uint32_t n_groups = n / G;
+  constexpr uint32_t CHUNK = 256 * K;
+
+  for (uint32_t base = blockIdx.x * CHUNK; base < n_groups; base += gridDim.x * CHUNK) {
+    F3 in[K][G];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t g = base + k * 256 + threadIdx.x;
+      if (g < n_groups) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) in[k][j] = s[g * G + j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t g = base + k * 256 + threadIdx.x;
+      if (g < n_groups) {
+        Px o[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          o[j] = finish<OUT>(front<CCMC, SH>(Px{in[k][j].x, in[k][j].y, in[k][j].z}, P, ip), P);
+        }
+        if constexpr (G == 1) {
+          reinterpret_cast<F3*>(d)[g] = F3{o[0].r, o[0].g, o[0].b};
+        } else if constexpr (G == 2) {
+          U3 q;
+          q.x = quant16(o[0].r) | (quant16(o[0].g) << 16);
+          q.y = quant16(o[0].b) | (quant16(o[1].r) << 16);
+          q.z = quant16(o[1].g) | (quant16(o[1].b) << 16);
+          reinterpret_cast<U3*>(d)[g] = q;
+        } else {
+          U3 q;
+          q.x = quant8(o[0].r) | (quant8(o[0].g) << 8) | (quant8(o[0].b) << 16) | (quant8(o[1].r) << 24);
+          q.y = quant8(o[1].g) | (quant8(o[1].b) << 8) | (quant8(o[2].r) << 16) | (quant8(o[2].g) << 24);
+          q.z = quant8(o[2].b) | (quant8(o[3].r) << 8) | (quant8(o[3].g) << 16) | (quant8(o[3].b) << 24);
+          reinterpret_cast<U3*>(d)[g] = q;
+        }
+      }
+    }
+  }
+  // the n % G pixels no full group covers
+  if (blockIdx.x == 0) {
+    const uint32_t px = n_groups * G + threadIdx.x;
+    if (px < n) {
+      const F3 v = s[px];
+      store_one<OUT>(d, px, finish<OUT>(front<CCMC, SH>(Px{v.x, v.y, v.z}, P, ip), P));
+    }
+  }
+}
+
+template <int CCMC, bool SH>
+static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
+                                   hipStream_t st) {
+  auto grid_for = [&](int G) {
+    const uint32_t K = 4 / G;
+    const uint64_t groups = (uint64_t)P.n_px / G;
+    uint64_t blocks = (groups + 256 * K - 1) / (256 * K);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    return dim3((unsigned)blocks, (unsigned)batch, 1);
+  };
+  switch (out_kind) {
+    case SS_OUT_F32_LINEAR:
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_LINEAR>), grid_for(1), dim3(256), 0, st, P, src, dst);
+      break;
+    case SS_OUT_F32_SRGB:
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_SRGB>), grid_for(1), dim3(256), 0, st, P, src, dst);
+      break;
+    case SS_OUT_U16_SRGB:
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U16_SRGB>), grid_for(2), dim3(256), 0, st, P, src, dst);
+      break;
+    case SS_OUT_U8_SRGB:
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_SRGB>), grid_for(4), dim3(256), 0, st, P, src, dst);
+      break;
+    case SS_OUT_U8_LINEAR:
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_LINEAR>), grid_for(4), dim3(256), 0, st, P, src, dst);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <int CCMC>
+static hipError_t launch_chain_sh(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
+                                  hipStream_t st) {
+  return P.sh ? launch_chain_out<CCMC, true>(P, batch, out_kind, src, dst, st)
+              : launch_chain_out<CCMC, false>(P, batch, out_kind, src, dst, st);
+}
+
+hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {
+  if (P.ccm_kind == SS_CCM_NONE) return launch_chain_sh<CCM_NONE>(P, batch, out_kind, src, dst, st);
+  if (P.ccm_terms == 3) return launch_chain_sh<CCM_LIN3>(P, batch, out_kind, src, dst, st);
+  if (P.ccm_kind == SS_CCM_CHEUNG) return launch_chain_sh<CCM_CHEUNG>(P, batch, out_kind, src, dst, st);
+  return launch_chain_sh<CCM_ROOT>(P, batch, out_kind, src, dst, st);
+}
+
+}  // namespace ss

@@ -1,0 +1,428 @@
+// Device-side pixel pipeline shared by the pointwise chain kernel and the fused
+// unsharp-mask kernel.  gfx950 only: transcendental work goes straight to the
+// hardware v_log_f32 / v_exp_f32 / v_sqrt_f32 instructions (1 ulp each), which
+// keeps the chain HBM-bound; all stage parameters arrive as one by-value kernel
+// argument so that they live in SGPRs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/scanspace.h"
+
+namespace ss {
+
+// Everything a kernel needs, derived on the host from ss_chain_desc.
+struct ChainParams {
+  int32_t height, width;
+  int64_t n_px;  // pixels per image
+
+  int32_t neg;
+  float neg_lo[3], neg_inv[3];
+  const float* neg_dev;  // [batch][8]
+
+  int32_t ccm_kind, ccm_terms;
+  float ccm[3 * SS_MAX_CCM_TERMS];
+
+  int32_t n_gain;
+  float gain[SS_MAX_GAIN_STAGES][3];
+  const float* gain0_dev;  // [batch]
+
+  int32_t sh;
+  float sh_ss, sh_hs;  // amounts * 0.05
+  float sh_log2f;      // log2(falloff_power)
+  int32_t sh_chroma;   // |amount| > 50 on either side
+
+  int32_t usm;
+  int32_t usm_r;            // taps = 2r+1
+  float usm_amount_scaled;  // amount / 50
+  float usm_thr;            // threshold / 100
+  float usm_inv_thr;        // 1 / usm_thr (0 when usm_thr == 0)
+  int32_t usm_chroma;       // amount > 30
+  float usm_chroma_k;       // amount / 100 * 0.1
+  float taps[2 * SS_MAX_USM_RADIUS + 1];
+
+  int32_t lab_io;
+  int32_t final_clip;
+
+  // sRGB -> XYZ rows pre-divided by the D65 white, and XYZ -> sRGB columns pre-multiplied by it
+  float m_fwd[9];
+  float m_inv[9];
+};
+
+struct Px {
+  float r, g, b;
+};
+struct Lab {
+  float L, a, b;
+};
+
+// ---- scalar helpers -----------------------------------------------------------------------
+
+__device__ __forceinline__ float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+// x ** p for x > 0 (callers select the linear segment for everything else)
+__device__ __forceinline__ float pow_pos(float x, float p) { return hw_exp2(hw_log2(x) * p); }
+
+// colour.algebra.spow with p = 1/2, 1/3, 1/4: sign(x) * |x| ** p, exact zero at zero
+__device__ __forceinline__ float sroot2(float x) { return copysignf(hw_sqrt(fabsf(x)), x); }
+__device__ __forceinline__ float sroot3(float x) { return copysignf(hw_exp2(hw_log2(fabsf(x)) * (1.0f / 3.0f)), x); }
+__device__ __forceinline__ float sroot4(float x) { return copysignf(hw_sqrt(hw_sqrt(fabsf(x))), x); }
+
+// sRGB inverse EOTF (colour.cctf_encoding): linear -> encoded
+__device__ __forceinline__ float srgb_encode(float L) {
+  const float hi = fmaf(1.055f, pow_pos(L, 1.0f / 2.4f), -0.055f);
+  const float lo = L * 12.92f;
+  return L <= 0.0031308f ? lo : hi;
+}
+
+// sRGB EOTF (colour.cctf_decoding): encoded -> linear
+__device__ __forceinline__ float srgb_decode(float V) {
+  const float t = fmaf(V, 1.0f / 1.055f, 0.055f / 1.055f);
+  const float hi = pow_pos(t, 2.4f);
+  const float lo = V * (1.0f / 12.92f);
+  return V <= 0.040449936f ? lo : hi;
+}
+
+// CIE 1976 intermediate lightness function and its inverse
+__device__ __forceinline__ float lab_f(float t) {
+  const float hi = hw_exp2(hw_log2(t) * (1.0f / 3.0f));
+  const float lo = fmaf(t, 841.0f / 108.0f, 16.0f / 116.0f);
+  return t > 0.008856451679035631f ? hi : lo;
+}
+__device__ __forceinline__ float lab_finv(float f) {
+  const float hi = f * f * f;
+  const float lo = (f - 16.0f / 116.0f) * (108.0f / 841.0f);
+  return f > 24.0f / 116.0f ? hi : lo;
+}
+
+// ---- colour space conversions (the reference treats its data as sRGB-ENCODED here) ----------
+
+__device__ __forceinline__ float rgb_to_fy(const Px p, const ChainParams& P) {
+  const float r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
+  return lab_f(fmaf(P.m_fwd[3], r, fmaf(P.m_fwd[4], g, P.m_fwd[5] * b)));
+}
+
+__device__ __forceinline__ Lab rgb_to_lab(const Px p, const ChainParams& P) {
+  const float r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
+  const float fx = lab_f(fmaf(P.m_fwd[0], r, fmaf(P.m_fwd[1], g, P.m_fwd[2] * b)));
+  const float fy = lab_f(fmaf(P.m_fwd[3], r, fmaf(P.m_fwd[4], g, P.m_fwd[5] * b)));
+  const float fz = lab_f(fmaf(P.m_fwd[6], r, fmaf(P.m_fwd[7], g, P.m_fwd[8] * b)));
+  Lab o;
+  o.L = fmaf(116.0f, fy, -16.0f);
+  o.a = 500.0f * (fx - fy);
+  o.b = 200.0f * (fy - fz);
+  return o;
+}
+
+// _lab_to_rgb: Lab -> XYZ -> sRGB (encoded) -> clip
+__device__ __forceinline__ Px lab_to_rgb(const Lab q, const ChainParams& P) {
+  const float fy = fmaf(q.L, 1.0f / 116.0f, 16.0f / 116.0f);
+  const float fx = fmaf(q.a, 1.0f / 500.0f, fy);
+  const float fz = fmaf(q.b, -1.0f / 200.0f, fy);
+  const float x = lab_finv(fx), y = lab_finv(fy), z = lab_finv(fz);
+  Px o;
+  o.r = clamp01(srgb_encode(fmaf(P.m_inv[0], x, fmaf(P.m_inv[1], y, P.m_inv[2] * z))));
+  o.g = clamp01(srgb_encode(fmaf(P.m_inv[3], x, fmaf(P.m_inv[4], y, P.m_inv[5] * z))));
+  o.b = clamp01(srgb_encode(fmaf(P.m_inv[6], x, fmaf(P.m_inv[7], y, P.m_inv[8] * z))));
+  return o;
+}
+
+// ---- colour correction ---------------------------------------------------------------------
+
+template <int T>
+__device__ __forceinline__ Px ccm_dot(const float (&e)[T], const float* __restrict__ M) {
+  Px o;
+  o.r = e[0] * M[0];
+  o.g = e[0] * M[T];
+  o.b = e[0] * M[2 * T];
+#pragma unroll
+  for (int t = 1; t < T; ++t) {
+    o.r = fmaf(e[t], M[t], o.r);
+    o.g = fmaf(e[t], M[T + t], o.g);
+    o.b = fmaf(e[t], M[2 * T + t], o.b);
+  }
+  return o;
+}
+
+__device__ __forceinline__ Px ccm_linear3(const Px p, const ChainParams& P) {
+  const float e[3] = {p.r, p.g, p.b};
+  return ccm_dot<3>(e, P.ccm);
+}
+
+// colour.characterisation.matrix_augmented_Cheung2004 term lists
+__device__ __forceinline__ Px ccm_cheung(const Px p, const ChainParams& P) {
+  const float R = p.r, G = p.g, B = p.b;
+  switch (P.ccm_terms) {
+    case 3: {
+      const float e[3] = {R, G, B};
+      return ccm_dot<3>(e, P.ccm);
+    }
+    case 5: {
+      const float e[5] = {R, G, B, R * G * B, 1.0f};
+      return ccm_dot<5>(e, P.ccm);
+    }
+    case 7: {
+      const float e[7] = {R, G, B, R * G, R * B, G * B, 1.0f};
+      return ccm_dot<7>(e, P.ccm);
+    }
+    case 8: {
+      const float e[8] = {R, G, B, R * G, R * B, G * B, R * G * B, 1.0f};
+      return ccm_dot<8>(e, P.ccm);
+    }
+    case 10: {
+      const float e[10] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, 1.0f};
+      return ccm_dot<10>(e, P.ccm);
+    }
+    case 11: {
+      const float e[11] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B, 1.0f};
+      return ccm_dot<11>(e, P.ccm);
+    }
+    case 14: {
+      const float e[14] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                           R * R * R, G * G * G, B * B * B, 1.0f};
+      return ccm_dot<14>(e, P.ccm);
+    }
+    case 16: {
+      const float e[16] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                           R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B};
+      return ccm_dot<16>(e, P.ccm);
+    }
+    case 17: {
+      const float e[17] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                           R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B, 1.0f};
+      return ccm_dot<17>(e, P.ccm);
+    }
+    case 19: {
+      const float e[19] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                           R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
+                           R * R * R, G * G * G, B * B * B};
+      return ccm_dot<19>(e, P.ccm);
+    }
+    case 20: {
+      const float e[20] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                           R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
+                           R * R * R, G * G * G, B * B * B, 1.0f};
+      return ccm_dot<20>(e, P.ccm);
+    }
+    default: {  // 22
+      const float e[22] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                           R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
+                           R * R * R, G * G * G, B * B * B, R * R * G * B, R * G * G * B, R * G * B * B};
+      return ccm_dot<22>(e, P.ccm);
+    }
+  }
+}
+
+// colour.characterisation.polynomial_expansion_Finlayson2015(root_polynomial_expansion=True)
+__device__ __forceinline__ Px ccm_rootpoly(const Px p, const ChainParams& P) {
+  const float R = p.r, G = p.g, B = p.b;
+  const float rg = R * G, gb = G * B, rb = R * B;
+  switch (P.ccm_terms) {
+    case 3: {
+      const float e[3] = {R, G, B};
+      return ccm_dot<3>(e, P.ccm);
+    }
+    case 6: {
+      const float e[6] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb)};
+      return ccm_dot<6>(e, P.ccm);
+    }
+    case 13: {
+      const float e[13] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
+                           sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
+                           sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B)};
+      return ccm_dot<13>(e, P.ccm);
+    }
+    default: {  // 22
+      const float e[22] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
+                           sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
+                           sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B),
+                           sroot4(R * R * rg), sroot4(R * R * rb), sroot4(G * G * rg),
+                           sroot4(G * G * gb), sroot4(B * B * rb), sroot4(B * B * gb),
+                           sroot4(R * rg * B), sroot4(G * rg * B), sroot4(B * rb * G)};
+      return ccm_dot<22>(e, P.ccm);
+    }
+  }
+}
+
+enum CcmClass { CCM_NONE = 0, CCM_LIN3 = 1, CCM_CHEUNG = 2, CCM_ROOT = 3, CCM_RUNTIME = 4 };
+
+template <int CCMC>
+__device__ __forceinline__ Px apply_ccm(const Px p, const ChainParams& P) {
+  if constexpr (CCMC == CCM_NONE) {
+    return p;
+  } else if constexpr (CCMC == CCM_LIN3) {
+    return ccm_linear3(p, P);
+  } else if constexpr (CCMC == CCM_CHEUNG) {
+    return ccm_cheung(p, P);
+  } else if constexpr (CCMC == CCM_ROOT) {
+    return ccm_rootpoly(p, P);
+  } else {
+    if (P.ccm_kind == SS_CCM_NONE) return p;
+    if (P.ccm_kind == SS_CCM_CHEUNG) return P.ccm_terms == 3 ? ccm_linear3(p, P) : ccm_cheung(p, P);
+    return ccm_rootpoly(p, P);
+  }
+}
+
+// ---- per-image parameters -------------------------------------------------------------------
+
+struct ImgParams {
+  float neg_lo[3], neg_inv[3];
+  float gain0[3];
+};
+
+__device__ __forceinline__ ImgParams load_img_params(const ChainParams& P, int img) {
+  ImgParams q;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    q.neg_lo[c] = P.neg_dev ? P.neg_dev[img * SS_NEG_PARAM_STRIDE + c] : P.neg_lo[c];
+    q.neg_inv[c] = P.neg_dev ? P.neg_dev[img * SS_NEG_PARAM_STRIDE + 3 + c] : P.neg_inv[c];
+    q.gain0[c] = P.gain0_dev ? P.gain0_dev[img] * P.gain[0][c] : P.gain[0][c];
+  }
+  return q;
+}
+
+// ---- stage 4: shadows / highlights on Lab (editingTools.py:508-536) --------------------------
+
+__device__ __forceinline__ Lab sh_on_lab(Lab q, const ChainParams& P) {
+  const float Ln = q.L * 0.01f;
+  const float hadj = P.sh_hs != 0.0f ? P.sh_hs * (hw_exp2(Ln * P.sh_log2f) - 1.0f) : 0.0f;
+  const float sadj = P.sh_ss != 0.0f ? P.sh_ss * (hw_exp2((1.0f - Ln) * P.sh_log2f) - 1.0f) : 0.0f;
+  const float total = (hadj + sadj) * 100.0f;
+  q.L = clampf(q.L + total, 0.0f, 100.0f);
+  if (P.sh_chroma) {
+    const float cs = 1.0f - clampf(fabsf(total) * (0.05f / 20.0f), 0.0f, 0.2f);
+    q.a *= cs;
+    q.b *= cs;
+  }
+  return q;
+}
+
+// ---- stages 1-4 on one pixel -----------------------------------------------------------------
+
+template <int CCMC, bool SH>
+__device__ __forceinline__ Px front(Px p, const ChainParams& P, const ImgParams& ip) {
+  if (P.neg) {
+    p.r = 1.0f - clamp01((clamp01(p.r) - ip.neg_lo[0]) * ip.neg_inv[0]);
+    p.g = 1.0f - clamp01((clamp01(p.g) - ip.neg_lo[1]) * ip.neg_inv[1]);
+    p.b = 1.0f - clamp01((clamp01(p.b) - ip.neg_lo[2]) * ip.neg_inv[2]);
+  }
+  p = apply_ccm<CCMC>(p, P);
+  if (P.n_gain > 0) {
+    p.r = clamp01(p.r * ip.gain0[0]);
+    p.g = clamp01(p.g * ip.gain0[1]);
+    p.b = clamp01(p.b * ip.gain0[2]);
+    if (P.n_gain > 1) {
+      p.r = clamp01(p.r * P.gain[1][0]);
+      p.g = clamp01(p.g * P.gain[1][1]);
+      p.b = clamp01(p.b * P.gain[1][2]);
+      if (P.n_gain > 2) {
+        p.r = clamp01(p.r * P.gain[2][0]);
+        p.g = clamp01(p.g * P.gain[2][1]);
+        p.b = clamp01(p.b * P.gain[2][2]);
+      }
+    }
+  }
+  if constexpr (SH) {
+    if (P.sh) {
+      if (P.lab_io) {
+        const Lab q = sh_on_lab(Lab{p.r, p.g, p.b}, P);
+        p = Px{q.L, q.a, q.b};
+      } else {
+        p = lab_to_rgb(sh_on_lab(rgb_to_lab(p, P), P), P);
+      }
+    }
+  }
+  return p;
+}
+
+// ---- stage 5 pointwise part: unsharp mask on (Ln, blurred Ln) (editingTools.py:767-809) -------
+
+__device__ __forceinline__ Lab usm_on_lab(const float Ln, const float a, const float b, const float Lb,
+                                          const ChainParams& P) {
+  float um = Ln - Lb;
+  if (P.usm_thr > 0.0f) {
+    const float es = fabsf(um);
+    um *= es > P.usm_thr ? 1.0f : es * P.usm_inv_thr;
+  }
+  const float hm = Ln > 0.9f ? 1.0f - (Ln - 0.9f) * 10.0f : 1.0f;
+  const float sm = Ln < 0.1f ? Ln * 10.0f : 1.0f;
+  const float ad = clampf(hm * sm, 0.1f, 1.0f);
+  Lab o;
+  o.L = clamp01(fmaf(um * P.usm_amount_scaled, ad, Ln)) * 100.0f;
+  if (P.usm_chroma) {
+    const float boost = fmaf(fabsf(um), P.usm_chroma_k, 1.0f);
+    o.a = clampf(a * boost, -127.0f, 127.0f);
+    o.b = clampf(b * boost, -127.0f, 127.0f);
+  } else {
+    o.a = a;
+    o.b = b;
+  }
+  return o;
+}
+
+// ---- stages 6-7: final clip, encoding, quantisation -------------------------------------------
+
+template <int OUT>
+__device__ __forceinline__ Px finish(Px p, const ChainParams& P) {
+  if (P.final_clip) {
+    p.r = clamp01(p.r);
+    p.g = clamp01(p.g);
+    p.b = clamp01(p.b);
+  }
+  if constexpr (OUT != SS_OUT_F32_LINEAR && OUT != SS_OUT_U8_LINEAR) {
+    p.r = srgb_encode(p.r);
+    p.g = srgb_encode(p.g);
+    p.b = srgb_encode(p.b);
+  }
+  return p;
+}
+
+// np.uint16(np.clip(x*65535, 0, 65535)) / np.uint8(np.clip(x*255, 0, 255)): truncation toward zero
+__device__ __forceinline__ uint32_t quant16(float x) { return (uint32_t)clampf(x * 65535.0f, 0.0f, 65535.0f); }
+__device__ __forceinline__ uint32_t quant8(float x) { return (uint32_t)clampf(x * 255.0f, 0.0f, 255.0f); }
+
+// lane granularity per output kind: G adjacent pixels per lane make a 12-byte store
+template <int OUT>
+struct OutTraits;
+template <>
+struct OutTraits<SS_OUT_F32_LINEAR> {
+  static constexpr int G = 1, BYTES = 4;
+};
+template <>
+struct OutTraits<SS_OUT_F32_SRGB> {
+  static constexpr int G = 1, BYTES = 4;
+};
+template <>
+struct OutTraits<SS_OUT_U16_SRGB> {
+  static constexpr int G = 2, BYTES = 2;
+};
+template <>
+struct OutTraits<SS_OUT_U8_SRGB> {
+  static constexpr int G = 4, BYTES = 1;
+};
+template <>
+struct OutTraits<SS_OUT_U8_LINEAR> {
+  static constexpr int G = 4, BYTES = 1;
+};
+
+// 12-byte, 4-byte-aligned vector types: one global_load/store_dwordx3 per lane, lanes contiguous
+struct __attribute__((aligned(4))) F3 {
+  float x, y, z;
+};
+struct __attribute__((aligned(4))) U3 {
+  uint32_t x, y, z;
+};
+
+// OpenCV BORDER_REFLECT (fedcba|abcdefgh|hgfedcb) coordinate map (cv::borderInterpolate)
+__device__ __forceinline__ int reflect_coord(int p, int len) {
+  if (len == 1) return 0;
+  while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p - 1 : 2 * len - p - 1;
+  return p;
+}
+
+}  // namespace ss

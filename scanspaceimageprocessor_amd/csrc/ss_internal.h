@@ -1,0 +1,43 @@
+// Host-side declarations shared by the translation units of libscanspace_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ss_device.h"
+
+namespace ss {
+
+// ---- chain.hip ---------------------------------------------------------------------------------
+// Pointwise fused chain (stages 1-4, 6, 7) over `batch` images.
+hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st);
+// Fused chain with the unsharp mask (stage 5): tile + halo recompute, separable blur in LDS.
+hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st);
+
+// ---- stats.hip ---------------------------------------------------------------------------------
+struct PercentileWork {
+  // all device pointers, sized for `batch` images of `n` samples
+  uint32_t* samples;  // [batch][3][n] clipped float bit patterns
+  uint32_t* hist;     // [batch][3 + 12 + 12][1024]
+  uint32_t* state;    // [batch][3][4][2] = {key prefix, residual rank}
+};
+size_t percentile_samples_bytes(int batch, int64_t n);
+size_t percentile_hist_bytes(int batch);
+size_t percentile_state_bytes(int batch);
+hipError_t launch_negative_params(const float* src, int height, int width, int batch, int step, int64_t n,
+                                  int64_t k_low, int64_t k_low_hi, double g_low, int64_t k_high, int64_t k_high_hi,
+                                  double g_high, int legacy, const PercentileWork& w, float* params,
+                                  ss_percentile_detail* detail, hipStream_t st);
+
+constexpr int kStatsBlocksPerImage = 8;
+hipError_t launch_exposure_stats(const float* thumbs, int height, int width, int batch, float lo, float hi,
+                                 double* partials /*[batch][kStatsBlocksPerImage][4]*/, double* stats, float* brightness,
+                                 hipStream_t st);
+hipError_t launch_exposure_multipliers(const float* brightness, int n, int ref_index, int first, int count,
+                                       float* mult, hipStream_t st);
+
+constexpr int kLabDetectBlocks = 1024;
+hipError_t launch_is_lab(const float* src, int64_t n_px, float* partials /*[kLabDetectBlocks][3]*/, int32_t* out,
+                         float* minmax, hipStream_t st);
+
+}  // namespace ss

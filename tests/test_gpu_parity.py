@@ -1,0 +1,346 @@
+"""Parity of the HIP path against the oracle and the reference's golden vectors.
+All tests call libscanspace_hip.so through its C ABI and need a real MI355X.
+
+Tolerances (from the project's north star): max-abs 1e-5 on float32 output, <= 1 LSB on
+16-bit (and 8-bit) output, exact order statistics for the percentiles."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden_input
+from gpu_util import DeviceBuffer, fit, run_chain_dev
+from oracle import chain as oc
+from oracle import inputs
+from oracle import leaves as lv
+from scanspaceimageprocessor_amd import _lib, default_context
+from scanspaceimageprocessor_amd.ImageProcessor import editingTools as et
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def swatches():
+    return inputs.synthetic_swatches()
+
+
+# ---- config 1: CCM + sRGB encode -------------------------------------------------------------
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (64, 96), (257, 389)])
+def test_config1_ccm_srgb_f32(swatches, shape):
+    M_T, M_R = swatches
+    img = inputs.linear_image(100 + shape[0], *shape)
+    got = run_chain_dev(img, ccm=fit(M_T, M_R), gains=[1.0], out="f32_srgb")[0]
+    want = oc.config1(img, M_T, M_R)
+    assert got.dtype == np.float32
+    assert np.max(np.abs(got - want)) <= F32_TOL
+
+
+def test_ccm_linear_output_is_unclipped(swatches):
+    M_T, M_R = swatches
+    img = inputs.wide_image(7, 40, 56)
+    got = run_chain_dev(img, ccm=fit(M_T, M_R), out="f32")[0]
+    want = lv.colour_correction(img, M_T, M_R)
+    assert want.min() < 0 and want.max() > 1
+    assert np.max(np.abs(got - want)) <= F32_TOL
+
+
+@pytest.mark.parametrize("out,scale,dtype", [("u16", 65535.0, np.uint16), ("u8", 255.0, np.uint8)])
+def test_quantised_outputs_within_one_lsb(swatches, out, scale, dtype):
+    M_T, M_R = swatches
+    img = inputs.linear_image(5, 123, 77)  # odd pixel count: exercises the tail path
+    got = run_chain_dev(img, ccm=fit(M_T, M_R), gains=[1.0], final_clip=True, out=out)[0]
+    c = np.clip(lv.colour_correction(img, M_T, M_R), 0, 1)
+    want = oc.encode_image(c, ".tiff", 16 if out == "u16" else 8)
+    assert got.dtype == dtype and want.dtype == dtype
+    diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert diff.max() <= 1
+    assert (diff != 0).mean() < 0.02  # flips only where the float value sits on a truncation boundary
+
+
+def test_u8_linear_preview(swatches):
+    M_T, M_R = swatches
+    img = inputs.linear_image(6, 50, 70)
+    got = run_chain_dev(img, ccm=fit(M_T, M_R), gains=[1.0], out="u8_linear")[0]
+    c = np.clip(lv.colour_correction(img, M_T, M_R), 0, 1)
+    want = np.uint8(np.clip(c * 255.0, 0, 255))  # imageProcessorWorker.py:922
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("terms", lv.CHEUNG_TERMS)
+def test_cheung_polynomial_terms(swatches, terms):
+    M_T, M_R = swatches
+    img = inputs.linear_image(terms, 48, 64)
+    ccm = fit(M_T, M_R, method="Cheung 2004", terms=terms)
+    got = run_chain_dev(img, ccm=ccm, out="f32")[0]
+    want = lv.colour_correction(img, M_T, M_R, "Cheung 2004", terms=terms)
+    # float32 evaluation error scales with sum |coef * term|
+    mag = np.abs(lv.expand(img.reshape(-1, 3).astype(np.float64), "Cheung 2004", terms=terms)) @ np.abs(ccm[0]).T
+    tol = max(F32_TOL, 4e-7 * float(mag.max()))
+    assert np.max(np.abs(got - want)) <= tol
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4])
+def test_root_polynomial_degrees(swatches, degree):
+    M_T, M_R = swatches
+    img = inputs.linear_image(20 + degree, 48, 64)
+    img[0, 0] = 0.0  # exact zeros go through the roots
+    ccm = fit(M_T, M_R, method="Finlayson 2015", degree=degree)
+    got = run_chain_dev(img, ccm=ccm, out="f32")[0]
+    want = lv.colour_correction(img, M_T, M_R, "Finlayson 2015", degree=degree, root_polynomial_expansion=True)
+    mag = np.abs(lv.expand(img.reshape(-1, 3).astype(np.float64), "Finlayson 2015", degree=degree)) @ np.abs(ccm[0]).T
+    tol = max(F32_TOL, 4e-7 * float(mag.max()))
+    assert np.max(np.abs(got - want)) <= tol
+    np.testing.assert_array_equal(got[0, 0], 0.0)
+
+
+# ---- negative film mode ------------------------------------------------------------------------
+
+
+def _negative_params(images, low, high, legacy):
+    ctx = default_context()
+    b, h, w, _ = images.shape
+    src = DeviceBuffer.from_array(ctx, images)
+    params = DeviceBuffer(ctx, b * _lib.SS_NEG_PARAM_STRIDE * 4)
+    detail = DeviceBuffer(ctx, b * C.sizeof(_lib.PercentileDetail))
+    try:
+        ctx.negative_params(src.ptr, h, w, b, low, high, legacy, params.ptr, detail.ptr)
+        ctx.sync()
+        p = params.to_array((b, _lib.SS_NEG_PARAM_STRIDE), np.float32)
+        raw = detail.to_array((b * C.sizeof(_lib.PercentileDetail),), np.uint8)
+        det = [_lib.PercentileDetail.from_buffer_copy(raw[i * C.sizeof(_lib.PercentileDetail):].tobytes())
+               for i in range(b)]
+        return p, det
+    finally:
+        src.free()
+        params.free()
+        detail.free()
+
+
+@pytest.mark.parametrize("shape,low,high", [((96, 128), 0.05, 0.995), ((1100, 1300), 0.05, 0.995),
+                                            ((700, 1000), 0.005, 0.995), ((64, 64), 0.0, 1.0), ((1, 1), 0.05, 0.995)])
+@pytest.mark.parametrize("legacy", [True, False])
+def test_percentiles_are_exact_order_statistics(shape, low, high, legacy):
+    imgs = np.stack([inputs.negative_image(31, *shape), inputs.wide_image(32, *shape)])
+    params, det = _negative_params(imgs, low, high, legacy)
+    for i in range(imgs.shape[0]):
+        d = {}
+        oc.invert_negative_auto(imgs[i], low, high, legacy=legacy, details=d)
+        (lo_a, lo_b, lo_idx, _), (hi_a, hi_b, hi_idx, _) = d["low_stats"], d["high_stats"]
+        assert det[i].step == d["step"] and det[i].n_samples == d["n"]
+        assert det[i].k_low == lo_idx and det[i].k_high == hi_idx
+        # bit-exact order statistics
+        np.testing.assert_array_equal(np.array(det[i].x_low_lo[:], np.float32), lo_a)
+        np.testing.assert_array_equal(np.array(det[i].x_low_hi[:], np.float32), lo_b)
+        np.testing.assert_array_equal(np.array(det[i].x_high_lo[:], np.float32), hi_a)
+        np.testing.assert_array_equal(np.array(det[i].x_high_hi[:], np.float32), hi_b)
+        np.testing.assert_allclose(np.array(det[i].p_low[:]), d["p_low"], rtol=0, atol=1e-12 if legacy else 0)
+        np.testing.assert_allclose(np.array(det[i].p_high[:]), d["p_high"], rtol=0, atol=1e-12 if legacy else 0)
+        np.testing.assert_allclose(params[i, :3], d["p_low"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(params[i, 3:6], 1.0 / d["denom"], rtol=2e-7)
+
+
+def test_percentiles_of_constant_and_two_valued_images():
+    a = np.full((200, 300, 3), 0.25, np.float32)
+    b = np.zeros((200, 300, 3), np.float32)
+    b[::2] = 1.0
+    params, det = _negative_params(np.stack([a, b]), 0.05, 0.995, True)
+    np.testing.assert_array_equal(np.array(det[0].x_low_lo[:]), 0.25)
+    np.testing.assert_array_equal(np.array(det[0].x_high_hi[:]), 0.25)
+    np.testing.assert_allclose(params[0, 3:6], 1000.0, rtol=1e-6)  # denom floor 1e-3
+    np.testing.assert_array_equal(np.array(det[1].x_low_lo[:]), 0.0)
+    np.testing.assert_array_equal(np.array(det[1].x_high_hi[:]), 1.0)
+
+
+@pytest.mark.parametrize("name", ["invert_small_default", "invert_small_q", "invert_wide", "invert_large_step2",
+                                  "ensure_enabled"])
+def test_negative_inversion_against_reference_vectors(golden, name, monkeypatch):
+    meta, data = golden
+    m = meta[name]
+    img = golden_input(m)
+    kw = {k: v for k, v in m["kwargs"].items() if k != "enabled"}
+    for legacy in (False, True):  # the vectors were made under numpy>=2; numpy<2 differs below 1e-6
+        monkeypatch.setattr(et, "NUMPY_LEGACY_PERCENTILE", legacy)
+        got = et.invert_negative_auto(img, **kw)
+        if m["stride"]:
+            got = got[:: m["stride"][0], :: m["stride"][1]]
+        assert got.dtype == np.float32
+        assert np.max(np.abs(got - data[name])) <= 2e-6
+
+
+def test_config3_negative_then_ccm_batch(swatches):
+    M_T, M_R = swatches
+    imgs = np.stack([inputs.negative_image(40 + i, 600, 900) for i in range(3)])
+    ctx = default_context()
+    src = DeviceBuffer.from_array(ctx, imgs)
+    params = DeviceBuffer(ctx, 3 * 32)
+    dst = DeviceBuffer(ctx, imgs.nbytes)
+    try:
+        ctx.negative_params(src.ptr, 600, 900, 3, 0.005, 0.995, True, params.ptr, None)
+        from scanspaceimageprocessor_amd.chain import make_desc
+        desc = make_desc(600, 900, 3, neg=True, neg_params_dev=params.ptr, ccm=fit(M_T, M_R), gains=[1.0], out="f32")
+        ctx.chain_run(desc, src.ptr, dst.ptr)
+        ctx.sync()
+        got = dst.to_array(imgs.shape, np.float32)
+    finally:
+        src.free(); params.free(); dst.free()
+    for i in range(3):
+        want = oc.config3(imgs[i], M_T, M_R, 0.005, 0.995, legacy=True)
+        assert np.max(np.abs(got[i] - want)) <= F32_TOL
+
+
+# ---- reference vectors through the drop-in Python entry points ---------------------------------
+
+MIRROR = {
+    "exposure": lambda img, kw: et.adjust_exposure(img, **kw),
+    "sh": lambda img, kw: et.adjust_shadows_highlights_combined(img, **kw),
+    "usm": lambda img, kw: et.adjust_sharpen(img, **kw),
+    "all": lambda img, kw: et.apply_all_adjustments(img, **kw),
+}
+
+
+@pytest.mark.parametrize("name", ["exposure_up", "exposure_down", "sh_basic", "sh_shadow_only", "sh_chroma",
+                                  "sh_falloff", "usm_r2_a50", "usm_r2_a1", "usm_r1_thr", "usm_r15_a80",
+                                  "all_basic", "all_exposure_only", "all_chart_mode_like"])
+def test_editing_tools_against_reference_vectors(golden, name):
+    meta, data = golden
+    m = meta[name]
+    img = golden_input(m)
+    before = img.copy()
+    got = MIRROR[name.split("_")[0]](img, m["kwargs"])
+    np.testing.assert_array_equal(img, before)  # input never modified
+    assert got is not img and got.dtype == np.float32 and got.shape == img.shape
+    assert np.max(np.abs(got - data[name])) <= F32_TOL
+
+
+@pytest.mark.parametrize("name", ["sh_lab_input", "usm_lab_input"])
+def test_lab_input_branch_against_reference_vectors(golden, name):
+    meta, data = golden
+    m = meta[name]
+    img = golden_input(m)
+    assert et._is_lab_image(img)
+    got = MIRROR[name.split("_")[0]](img, m["kwargs"])
+    # Lab units (L 0..100, a/b +-127): 1e-5 of full scale
+    assert np.max(np.abs(got - data[name])) <= 1e-3
+
+
+def test_neutral_settings_return_the_input_object():
+    img = inputs.linear_image(1, 8, 8)
+    assert et.adjust_exposure(img, 0) is img
+    assert et.adjust_shadows_highlights_combined(img, 0, 0) is img
+    assert et.adjust_sharpen(img, 0) is img
+    assert et.adjust_white_balance(img, 5500, 5500) is img
+    assert et.ensure_positive_if_negative(img, False) is img
+    flat = np.zeros((8, 8), np.float32)
+    assert et.invert_negative_auto(flat) is flat  # not (H,W,3): returned unchanged
+    out = et.apply_all_adjustments(img)
+    assert out is not img and np.array_equal(out, img)
+    assert not et._is_lab_image(img)
+
+
+# ---- config 2 / config 4 ------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("shape", [(3, 5), (33, 129), (200, 300), (257, 389)])
+@pytest.mark.parametrize("amount", [1.0, 50.0])
+def test_config2_ccm_gain_usm_u16(swatches, shape, amount):
+    M_T, M_R = swatches
+    img = inputs.smooth_image(60, *shape)
+    mult = 1.17
+    got = run_chain_dev(img, ccm=fit(M_T, M_R), gains=[mult], usm=(amount, 2.0, 0.0), final_clip=True, out="u16")[0]
+    want = oc.config2(img, M_T, M_R, mult, amount, 2.0, 0.0)
+    diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert diff.max() <= 1
+
+
+@pytest.mark.parametrize("radius,threshold", [(0.5, 0.0), (1.0, 3.0), (1.5, 0.0), (3.0, 1.0), (5.0, 0.0)])
+def test_usm_all_radii_f32(radius, threshold):
+    img = inputs.smooth_image(61, 150, 210)
+    got = run_chain_dev(img, usm=(60.0, radius, threshold), out="f32")[0]
+    want = oc.adjust_sharpen(img, 60.0, radius, threshold)
+    assert np.max(np.abs(got - want)) <= F32_TOL
+
+
+def test_usm_of_constant_image_is_identity_after_round_trip():
+    img = np.full((70, 140, 3), 0.5, np.float32)
+    got = run_chain_dev(img, usm=(80.0, 2.0, 0.0), out="f32")[0]
+    assert np.max(np.abs(got - 0.5)) <= 2e-6
+
+
+@pytest.mark.parametrize("degree", [2, 3])
+def test_config4_rootpoly_shadows_highlights(swatches, degree):
+    M_T, M_R = swatches
+    img = inputs.linear_image(70 + degree, 160, 240)
+    ccm = fit(M_T, M_R, method="Finlayson 2015", degree=degree)
+    got = run_chain_dev(img, ccm=ccm, gains=[1.0], sh=(0.5, -0.5, 7.0), final_clip=True, out="f32")[0]
+    want = oc.config4(img, M_T, M_R, degree, 0.5, -0.5)
+    assert np.max(np.abs(got - want)) <= F32_TOL
+
+
+def test_worker_chart_path_with_all_stages(swatches):
+    M_T, M_R = swatches
+    img = inputs.negative_image(80, 120, 180)
+    d = {}
+    oc.invert_negative_auto(img, 0.05, 0.995, legacy=True, details=d)
+    neg = (d["p_low"], 1.0 / d["denom"])
+    wb = et.calculate_white_balance_multipliers(5200.0, 6100.0, 0.0)
+    got = run_chain_dev(img, neg=neg, ccm=fit(M_T, M_R), gains=[1.3, wb, 2.0 ** 0.4],
+                        sh=(30.0 / 70, 0.2 * 1.3, 7.0), final_clip=True, out="f32")[0]
+    want = oc.worker_chart_path(img, M_T, M_R, multiplier=1.3, negative_mode=True, exposure_adj=0.4,
+                                shadow_adj=30.0, highlight_adj=0.2, wb_gains=wb)
+    assert np.max(np.abs(got - want)) <= F32_TOL
+
+
+# ---- dataset exposure normalisation ---------------------------------------------------------------
+
+
+def test_exposure_stats_and_multipliers():
+    ctx = default_context()
+    rng = np.random.default_rng(9)
+    n, h, w = 7, 341, 512
+    thumbs = np.stack([inputs.linear_image(90 + i, h, w) * np.float32(2.0 ** rng.uniform(-0.5, 0.5)) for i in range(n)])
+    thumbs[3] = 0.99  # mask empty -> falls back to the plain mean
+    thumbs[5] = 0.0   # brightness 0 -> multiplier 1.0
+    src = DeviceBuffer.from_array(ctx, thumbs)
+    stats = DeviceBuffer(ctx, n * 4 * 8)
+    bright = DeviceBuffer(ctx, n * 4)
+    mult = DeviceBuffer(ctx, n * 4)
+    try:
+        ctx.exposure_stats(src.ptr, h, w, n, 0.06, 0.96, stats.ptr, bright.ptr)
+        ctx.exposure_multipliers(bright.ptr, n, None, 0, n, mult.ptr)
+        ctx.sync()
+        b = bright.to_array((n,), np.float32)
+        s = stats.to_array((n, 4), np.float64)
+        m_mean = mult.to_array((n,), np.float32)
+        ctx.exposure_multipliers(bright.ptr, n, 2, 1, 4, mult.ptr)
+        ctx.sync()
+        m_chart = mult.to_array((4,), np.float32)
+    finally:
+        src.free(); stats.free(); bright.free(); mult.free()
+    want_b = [oc.image_brightness(t, 0.06, 0.96) for t in thumbs]
+    np.testing.assert_allclose(b, want_b, rtol=1e-6, atol=0)
+    for i, t in enumerate(thumbs):
+        lum = 0.2126 * t[:, :, 0] + 0.7152 * t[:, :, 1] + 0.0722 * t[:, :, 2]
+        mask = (lum > np.float32(0.06)) & (lum < np.float32(0.96))
+        assert s[i, 1] == mask.sum() and s[i, 3] == lum.size  # exact counts: the mask is bit-exact
+    np.testing.assert_allclose(m_mean, oc.exposure_multipliers(want_b, None), rtol=1e-6)
+    np.testing.assert_allclose(m_chart, oc.exposure_multipliers(want_b, 2)[1:5], rtol=1e-6)
+    assert m_mean[5] == 1.0
+
+
+# ---- errors ------------------------------------------------------------------------------------------
+
+
+def test_bad_descriptors_are_rejected():
+    img = inputs.linear_image(1, 8, 8)
+    with pytest.raises(_lib.ScanSpaceError) as e:
+        run_chain_dev(img, ccm=(np.zeros((3, 4)), _lib.SS_CCM_CHEUNG, 4))
+    assert e.value.code == _lib.SS_ERR_INVALID
+    with pytest.raises(_lib.ScanSpaceError):
+        run_chain_dev(img, usm=(10.0, 9.0, 0.0))  # 55-tap kernel: unsupported
+    with pytest.raises(_lib.ScanSpaceError):
+        run_chain_dev(img, sh=(1.0, 0.0, 7.0), lab_io=True, final_clip=True)
