@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: megapixels/s of the full 24 MP correction chain.
+
+Workload (BASELINE.json configs[1], per GPU): a batch of 64 synthetic 24 MP (4000 x 6000) float32
+linear RGB images resident in HBM ->  dataset exposure normalisation (per-image thumbnail
+statistics, [RCCL all-gather when N > 1], multipliers) -> ColorChecker CCM (Cheung 2004, 3 terms)
+-> exposure gain -> clip -> unsharp mask (radius 2, amount 1.0) -> clip -> sRGB encode ->
+16-bit truncating quantise.  One "step" = one pass over the batch.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` is whole-job MP/s (all ranks) with inputs resident in HBM;
+`roofline` prices the fused unsharp-mask kernel against the 8 TB/s HBM peak using its ALGORITHMIC
+bytes (12 B/px float32 in + 6 B/px uint16 out = 18 B/px); `cpu_baseline` times the numpy
+restatement of the reference's path (oracle/, a port: the reference itself cannot be imported
+on the GPU box) on one 24 MP image with one thread.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 4000, 6000
+THUMB_H, THUMB_W = 341, 512
+SHADOW_LIMIT, HIGHLIGHT_LIMIT = 0.06, 0.96
+HBM_PEAK_GBS = 8000.0
+ALGO_BYTES_PER_PX = 18.0  # 12 in (float32 RGB) + 6 out (uint16 RGB)
+
+
+def synthetic_swatches():
+    """Same recipe as oracle.inputs.synthetic_swatches (kept local: the product path never imports oracle/)."""
+    r = np.random.default_rng(7)
+    M_R = 0.03 + 0.87 * r.random((24, 3))
+    c = np.random.default_rng(8)
+    A = np.eye(3) + 0.15 * (c.random((3, 3)) * 2.0 - 1.0)
+    M_T = M_R @ A.T + c.normal(0.0, 0.002, size=(24, 3))
+    return M_T.astype(np.float32), M_R.astype(np.float64)
+
+
+def cpu_baseline(amount):
+    """Time the numpy restatement of the reference path on ONE 24 MP image, single-threaded."""
+    from oracle import chain as oc
+    from oracle import inputs
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    M_T, M_R = inputs.synthetic_swatches()
+    img = inputs.linear_image(1234, H, W)
+    t0 = time.perf_counter()
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            oc.config2(img, M_T, M_R, 1.1, amount, 2.0, 0.0)
+    else:
+        oc.config2(img, M_T, M_R, 1.1, amount, 2.0, 0.0)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(H * W / 1e6 / dt, 3), "unit": "MP/s", "cores": 1, "kind": "port",
+        "sample": f"1 image of {H}x{W} (24 MP) through oracle.chain.config2 (float64 numpy restatement of the "
+                  f"reference CPU path, BLAS limited to 1 thread), {dt:.1f} s; host has {os.cpu_count()} logical CPUs",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--amount", type=float, default=1.0, help="unsharp-mask amount (BASELINE: 1.0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from scanspaceimageprocessor_amd import Context
+    from scanspaceimageprocessor_amd.chain import make_desc
+    from scanspaceimageprocessor_amd.colour_fit import matrix_colour_correction
+    from scanspaceimageprocessor_amd.dataset import ExposureNormaliser, shard_range
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    n_total = B * world
+    first, count = shard_range(n_total, rank, world)
+    assert count == B
+
+    # ---- synthetic dataset, generated on the device (not timed) ----
+    scales = 2.0 ** np.random.default_rng(9).uniform(-0.5, 0.5, size=n_total)
+    images = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+    thumbs = torch.empty((B, THUMB_H, THUMB_W, 3), dtype=torch.float32, device=dev)
+    for i in range(B):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + first + i)
+        img = torch.rand((H, W, 3), generator=g, device=dev, dtype=torch.float32)
+        img.pow_(2.2).mul_(0.9 * float(scales[first + i])).clamp_(0.0, 1.0)
+        images[i] = img
+        t = torch.nn.functional.adaptive_avg_pool2d(img.permute(2, 0, 1).unsqueeze(0), (THUMB_H, THUMB_W))
+        thumbs[i] = t.squeeze(0).permute(1, 2, 0)
+        del img, t
+    out = torch.empty((B, H, W, 3), dtype=torch.int16, device=dev)  # uint16 payload
+
+    ctx = Context(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)  # library kernels and the collective share torch's stream
+    norm = ExposureNormaliser(ctx, n_total, rank, world, SHADOW_LIMIT, HIGHLIGHT_LIMIT)
+    gains = norm.gains
+
+    M_T, M_R = synthetic_swatches()
+    ccm = matrix_colour_correction(M_T, M_R)  # Cheung 2004, 3 terms: the reference's only call form
+    desc = make_desc(H, W, B, ccm=ccm, gains=[1.0], gain0_dev=gains.data_ptr(), usm=(args.amount, 2.0, 0.0),
+                     final_clip=True, out="u16")
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(k=None):
+        norm.run(thumbs.data_ptr(), THUMB_H, THUMB_W)  # stats -> [all-gather] -> multipliers into `gains`
+        if k is not None:
+            ev[k][0].record(stream)
+        ctx.chain_run(desc, images.data_ptr(), out.data_ptr())
+        if k is not None:
+            ev[k][1].record(stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    px_per_launch = float(B) * H * W
+    achieved_gbs = ALGO_BYTES_PER_PX * px_per_launch / (kernel_ms * 1e-3) / 1e9
+    mp_total = n_total * H * W / 1e6 * args.steps
+    value = mp_total / elapsed
+
+    # sanity: the output must not be all zeros / all saturated (catches a silently skipped launch)
+    sample = out[0, ::400, ::600].to(torch.int32) & 0xFFFF
+    assert int(sample.max()) > 0 and int(sample.min()) < 65535, "implausible output"
+    g = gains.cpu().numpy()
+    assert np.all(np.isfinite(g)) and abs(float(np.mean(g)) - 1.0) < 0.2, "implausible exposure multipliers"
+
+    if rank == 0:
+        line = {
+            "metric": "megapixels/sec (whole node), full 24MP correction chain",
+            "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{B}x24MP per GPU: exposure normalisation + Cheung-2004 3x3 CCM + gain + clip + unsharp "
+                            f"mask (radius 2, amount {args.amount:g}) + sRGB encode + 16-bit quantise "
+                            "(BASELINE.json configs[1])",
+                "images_per_gpu": B, "height": H, "width": W, "parallelism": f"image-sharded x{world}",
+                "collective": "all_gather of per-image brightness (RCCL)" if world > 1 else "none",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "usm_kernel<6, U16, TH>", "achieved": round(achieved_gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "algorithmic_bytes_per_px": ALGO_BYTES_PER_PX,
+                "px_per_launch": px_per_launch, "kernel_ms": round(kernel_ms, 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.amount)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

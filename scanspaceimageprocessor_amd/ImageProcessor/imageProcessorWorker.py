@@ -1,0 +1,347 @@
+"""Per-image worker of the correction chain: the counterpart of the reference's
+``ImageProcessor/imageProcessorWorker.py`` (``ImageCorrectionWorker``, lines 203-977) with the
+pixel work done by the gfx950 kernels of libscanspace_hip.so.
+
+Kept from the reference: constructor arguments and defaults, the method names ``load_image``,
+``apply_colour_correction``, ``apply_image_adjustments``, ``encode_image``, ``run``; the order
+load -> [negative inversion] -> CCM -> exposure multiplier -> clip -> adjustments -> clip -> encode;
+the three signals ``log(str)``, ``status(path, state, seconds, out_path)`` (one-argument
+``'started'`` form in network mode) and ``preview([uint8_array, out_path])``; and the rule that a
+failing image is reported as ``'error'`` and the loop continues.
+
+Different by design: ``run`` keeps each image on the GPU between its steps (one upload, one fused
+kernel pass per output, downloads of the encoded result and of the 8-bit preview only).  RAW
+decoding (rawpy) and file encoding (imageio / tifffile) stay on the host and are looked up at
+call time; metadata embedding, path schemas and luminance masking are outside this package.
+"""
+
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from .. import _lib
+from ..chain import make_desc
+from ..colour_fit import matrix_colour_correction
+from .._lib import default_context
+from . import editingTools
+from .editingTools import apply_all_adjustments, ensure_positive_if_negative
+
+RAW_EXTENSIONS = ('.nef', '.cr2', '.cr3', '.dng', '.arw', '.raw')
+OUTPUT_FORMATS = ('.jpg', '.png', '.tiff', '.exr')
+
+
+def _default_reference_swatches():
+    """Linear-sRGB values of the 'ColorChecker24 - After November 2014' chart, CAT02-adapted to D65
+    (reference imageProcessorWorker.py:116-125).  The table lives in colour-science; without that
+    package the caller supplies it through ``set_reference_swatches``."""
+    try:
+        import colour  # type: ignore
+        from colour import RGB_COLOURSPACES  # type: ignore
+    except Exception:
+        return None
+    reference = colour.CCS_COLOURCHECKERS['ColorChecker24 - After November 2014']
+    return colour.XYZ_to_RGB(
+        colour.xyY_to_XYZ(list(reference.data.values())), RGB_COLOURSPACES['sRGB'],
+        illuminant=reference.illuminant, chromatic_adaptation_transform="CAT02", apply_cctf_encoding=False)
+
+
+reference_swatches = _default_reference_swatches()
+
+
+def set_reference_swatches(swatches) -> None:
+    """Install the 24x3 reference (target) swatch table used by ``apply_colour_correction``."""
+    global reference_swatches
+    swatches = np.asarray(swatches, dtype=np.float64)
+    if swatches.ndim != 2 or swatches.shape[1] != 3:
+        raise ValueError(f"reference swatches must be (N, 3), got {swatches.shape}")
+    reference_swatches = swatches
+
+
+class _Signal:
+    """Minimal stand-in for a Qt signal: ``connect(fn)`` / ``emit(*args)``."""
+
+    def __init__(self):
+        self._slots = []
+
+    def connect(self, fn):
+        self._slots.append(fn)
+
+    def emit(self, *args):
+        for fn in list(self._slots):
+            fn(*args)
+
+
+class WorkerSignals:
+    """Qt-free signals object (the reference ships one for its network mode, networkProcessor.py:3471)."""
+
+    def __init__(self):
+        self.log = _Signal()
+        self.status = _Signal()
+        self.preview = _Signal()
+
+
+class ImageCorrectionWorker:
+    def __init__(self, images, swatches, output_folder, signals, jpeg_quality=100,
+                 rename_map=None, name_base='', padding=0, export_masked=False,
+                 output_format: str = '.jpg', tiff_bitdepth=8, exr_colorspace=None,
+                 export_schema: str = "", use_export_schema: bool = True,
+                 custom_name: str = "", root_folder: str = "", from_network=False,
+                 network_output_path: str = "", group_name: str = "",
+                 use_chart: bool = True, exposure_adj: float = 0.0,
+                 shadow_adj: float = 0.0, highlight_adj: float = 0.0,
+                 white_balance_adj: int = 5500, denoise_strength: float = 0.0,
+                 sharpen_amount: float = 0.0,
+                 negative_mode: bool = False,
+                 negative_low_pct: float = 0.05,
+                 negative_high_pct: float = 0.995):
+        self.images = images
+        self.swatches = swatches
+        self.output_folder = output_folder
+        self.signals = signals if signals is not None else WorkerSignals()
+        self.jpeg_quality = jpeg_quality
+        self.output_format = output_format
+        self.tiff_bitdepth = tiff_bitdepth
+        self.exr_colorspace = exr_colorspace
+        self.rename_map = rename_map or {}
+        self.name_base = name_base
+        self.padding = padding
+        self.export_masked = export_masked
+        self.cancelled = False
+        self.export_schema = export_schema
+        self.use_export_schema = use_export_schema
+        self.custom_name = custom_name
+        self.root_folder = root_folder
+        self.from_network = from_network
+        self.network_output_path = network_output_path
+        self.group_name = group_name
+        self.use_chart = use_chart
+        self.exposure_adj = exposure_adj
+        self.shadow_adj = shadow_adj
+        self.highlight_adj = highlight_adj
+        self.white_balance_adj = white_balance_adj
+        self.denoise_strength = denoise_strength
+        self.sharpen_amount = sharpen_amount
+        self.negative_mode = negative_mode
+        self.negative_low_pct = negative_low_pct
+        self.negative_high_pct = negative_high_pct
+        # host-side hooks (defaults look the libraries up when first needed)
+        self.raw_loader = None     # callable(path) -> (H,W,3) float32 in [0,1]
+        self.image_writer = None   # callable(path, array, fmt)
+        self._ccm = None
+
+    def cancel(self):
+        self.cancelled = True
+
+    # ------------------------------------------------------------------ reference method surface
+
+    def load_image(self, img_path: str) -> np.ndarray:
+        """RAW -> float32 linear sRGB in [0,1] on the host (rawpy/LibRaw), then the optional
+        negative inversion (reference imageProcessorWorker.py:291-325)."""
+        raw_img_float = self._decode_raw(img_path)
+        return ensure_positive_if_negative(raw_img_float, enabled=self.negative_mode,
+                                           low_percentile=self.negative_low_pct,
+                                           high_percentile=self.negative_high_pct)
+
+    def apply_colour_correction(self, img_array: np.ndarray) -> np.ndarray:
+        """``colour.colour_correction(img, swatches, reference_swatches)`` with the defaults
+        (reference imageProcessorWorker.py:327-338): unclipped float output."""
+        h, w, _ = img_array.shape
+        desc = make_desc(h, w, 1, ccm=self._fit(), out="f32")
+        out, _ = default_context().chain_run_host(desc, img_array)
+        return out
+
+    def apply_image_adjustments(self, img_array: np.ndarray, img_path: str) -> np.ndarray:
+        """No-chart mode (reference imageProcessorWorker.py:340-370): sharpen radius 1.0, threshold 0."""
+        current_wb = self._extract_white_balance_from_exif(img_path)
+        return apply_all_adjustments(
+            img_array, exposure=self.exposure_adj, shadows=self.shadow_adj, highlights=self.highlight_adj,
+            current_wb=current_wb, target_wb=self.white_balance_adj, wb_tint=0.0,
+            denoise_strength=self.denoise_strength, sharpen_amount=self.sharpen_amount,
+            sharpen_radius=1.0, sharpen_threshold=0.0)
+
+    def encode_image(self, img_array: np.ndarray, output_format: str) -> np.ndarray:
+        """sRGB encoding + truncating quantisation (reference imageProcessorWorker.py:579-602)."""
+        kind = self._out_kind(output_format)
+        if kind == _lib.SS_OUT_F32_LINEAR:
+            return img_array
+        h, w, _ = img_array.shape
+        out, _ = default_context().chain_run_host(make_desc(h, w, 1, out=kind), img_array)
+        return out
+
+    def _has_non_default_adjustments(self) -> bool:
+        return (self.exposure_adj != 0.0 or self.shadow_adj != 0.0 or self.highlight_adj != 0.0
+                or self.white_balance_adj != 5500 or self.denoise_strength != 0.0 or self.sharpen_amount != 0.0)
+
+    def _extract_white_balance_from_exif(self, img_path: str) -> float:
+        """The reference re-opens the RAW file to estimate the as-shot temperature
+        (imageProcessorWorker.py:397-577, host I/O); this package takes it from
+        ``image_metadata_map[path]['current_wb']`` when the caller provides it, else daylight."""
+        meta = getattr(self, "image_metadata_map", {}).get(img_path) or {}
+        try:
+            return float(meta.get('current_wb', 5500.0))
+        except (TypeError, ValueError):
+            return 5500.0
+
+    # ------------------------------------------------------------------ fused device path
+
+    def _fit(self):
+        if self._ccm is None:
+            if reference_swatches is None:
+                raise RuntimeError("reference_swatches is not set: colour-science is not installed; call "
+                                   "imageProcessorWorker.set_reference_swatches(table_24x3)")
+            self._ccm = matrix_colour_correction(self.swatches, reference_swatches)
+        return self._ccm
+
+    def _out_kind(self, output_format: str) -> int:
+        if output_format in ('.png', '.jpg', '.jpeg'):
+            return _lib.SS_OUT_U8_SRGB
+        if output_format == '.tiff':
+            return _lib.SS_OUT_U16_SRGB if self.tiff_bitdepth == 16 else _lib.SS_OUT_U8_SRGB
+        return _lib.SS_OUT_F32_LINEAR
+
+    def _multiplier(self, img_path: str) -> float:
+        """Exposure-normalisation multiplier from the metadata map (reference imageProcessorWorker.py:863-873)."""
+        multiplier = 1.0
+        if hasattr(self, "image_metadata_map"):
+            meta = self.image_metadata_map.get(img_path)
+            if meta is not None:
+                try:
+                    multiplier = float(meta.get('average_exposure'))
+                except (TypeError, ValueError):
+                    multiplier = 1.0
+        return multiplier
+
+    def chain_stages(self, img_path: str) -> dict:
+        """The reference's steps 5 of ``run`` as chain stages (keyword arguments of ``make_desc``)."""
+        if self.use_chart:
+            kw = dict(ccm=self._fit(), gains=[self._multiplier(img_path)])  # gain + clip always runs
+            if self._has_non_default_adjustments():
+                current_wb = self._extract_white_balance_from_exif(img_path)
+                target_wb = self.white_balance_adj if self.white_balance_adj != 5500 else current_wb
+                adj = editingTools.adjustment_stages(
+                    exposure=self.exposure_adj, shadows=self.shadow_adj, highlights=self.highlight_adj,
+                    current_wb=current_wb, target_wb=target_wb, wb_tint=0.0,
+                    denoise_strength=self.denoise_strength)  # chart mode never passes the sharpen arguments
+                kw["gains"] += adj.pop("gains")
+                kw.update(adj)
+        else:
+            current_wb = self._extract_white_balance_from_exif(img_path)
+            kw = editingTools.adjustment_stages(
+                exposure=self.exposure_adj, shadows=self.shadow_adj, highlights=self.highlight_adj,
+                current_wb=current_wb, target_wb=self.white_balance_adj, wb_tint=0.0,
+                denoise_strength=self.denoise_strength, sharpen_amount=self.sharpen_amount,
+                sharpen_radius=1.0, sharpen_threshold=0.0)
+        kw["final_clip"] = True
+        return kw
+
+    def process_array(self, raw_img_float: np.ndarray, img_path: str = ""):
+        """Steps 5-7 of the reference's ``run`` on one decoded image, resident on the GPU:
+        returns ``(encoded, preview_uint8)``.  ``raw_img_float`` is the output of the RAW decode
+        BEFORE negative inversion (the inversion runs on the device here)."""
+        ctx = default_context()
+        img = np.ascontiguousarray(raw_img_float, dtype=np.float32)
+        h, w, _ = img.shape
+        kind = self._out_kind(self.output_format)
+        kw = self.chain_stages(img_path)
+        src = ctx.malloc(img.nbytes)
+        dst = ctx.malloc(img.nbytes)
+        neg = ctx.malloc(_lib.SS_NEG_PARAM_STRIDE * 4) if self.negative_mode else None
+        try:
+            ctx.upload(src, img)
+            if self.negative_mode:
+                ctx.negative_params(src, h, w, 1, self.negative_low_pct, self.negative_high_pct,
+                                    editingTools.NUMPY_LEGACY_PERCENTILE, neg)
+                kw.update(neg=True, neg_params_dev=neg)
+            encoded = np.empty(img.shape, dtype=_lib.OUT_DTYPES[kind])
+            ctx.chain_run(make_desc(h, w, 1, out=kind, **kw), src, dst)
+            ctx.download(encoded, dst)
+            if encoded.dtype == np.uint8:
+                preview = encoded
+            else:
+                preview = np.empty(img.shape, dtype=np.uint8)
+                ctx.chain_run(make_desc(h, w, 1, out="u8_linear", **kw), src, dst)
+                ctx.download(preview, dst)
+            return encoded, preview
+        finally:
+            ctx.free(src)
+            ctx.free(dst)
+            if neg:
+                ctx.free(neg)
+
+    # ------------------------------------------------------------------ host I/O hooks
+
+    def _decode_raw(self, img_path: str) -> np.ndarray:
+        if self.raw_loader is not None:
+            return np.asarray(self.raw_loader(img_path), dtype=np.float32)
+        self.signals.log.emit(f"[RAW] Using original path for rawpy: {img_path}")
+        import rawpy  # host decode stays on LibRaw
+
+        with rawpy.imread(img_path) as raw:
+            rgb = raw.postprocess(output_bps=16, gamma=(1, 1), no_auto_bright=True, use_camera_wb=True,
+                                  output_color=rawpy.ColorSpace.sRGB)
+            return np.array(rgb, dtype=np.float32) / 65535.0
+
+    def _write(self, out_path: str, encoded: np.ndarray, ext: str) -> None:
+        if self.image_writer is not None:
+            self.image_writer(out_path, encoded, ext)
+            return
+        if ext in ('.jpg', '.jpeg'):
+            import imageio
+
+            imageio.imwrite(out_path, encoded, quality=self.jpeg_quality)
+        elif ext == '.png':
+            import imageio
+
+            imageio.imwrite(out_path, encoded)
+        elif ext == '.tiff':
+            from tifffile import tifffile
+
+            with tifffile.TiffWriter(out_path) as tw:
+                tw.write(encoded)
+        else:
+            raise NotImplementedError("EXR export goes through OpenImageIO in the reference; supply image_writer")
+
+    def construct_export_path(self, img_path: str) -> str:
+        base = os.path.splitext(os.path.basename(img_path))[0]
+        return os.path.join(self.output_folder, base + self.output_format)
+
+    # ------------------------------------------------------------------ main loop
+
+    def run(self):
+        """Reference imageProcessorWorker.py:815-977 without metadata embedding and masking."""
+        ext = self.output_format
+        for img_path in self.images:
+            t0 = time.time()
+            out_path = None
+            try:
+                out_path = self.construct_export_path(img_path)
+                if self.from_network:
+                    self.signals.status.emit('started')
+                else:
+                    self.signals.status.emit(img_path, 'started', time.time() - t0, out_path)
+                self.signals.log.emit(f"[Worker] Starting {os.path.basename(img_path)} -> {os.path.basename(out_path)}")
+                try:
+                    raw_img_float = self._decode_raw(img_path)
+                except Exception as e:
+                    self.signals.log.emit(f"[Image Load Error] {img_path}: {e}")
+                    self.signals.status.emit(img_path, 'error', time.time() - t0, out_path)
+                    continue
+                if self.cancelled:
+                    self.signals.log.emit("[Worker] Cancelled by user. Exiting thread.")
+                    self.signals.status.emit(img_path, 'cancelled', time.time() - t0, out_path)
+                    return
+                encoded, preview = self.process_array(raw_img_float, img_path)
+                del raw_img_float
+                self._write(out_path, encoded, ext)
+                self.signals.log.emit(f"[Saved] {out_path}")
+                self.signals.preview.emit([preview, out_path])
+                self.signals.status.emit(img_path, 'finished', time.time() - t0, out_path)
+            except Exception as e:
+                self.signals.log.emit(f"[Processing Error] {img_path}: {e}")
+                if out_path is None:
+                    out_path = os.path.join(self.output_folder,
+                                            os.path.splitext(os.path.basename(img_path))[0] + self.output_format)
+                self.signals.status.emit(img_path, 'error', time.time() - t0, out_path)

@@ -1,0 +1,83 @@
+"""Batches of images sharded over the GPUs of one node, one process per GPU.
+
+Images are independent, so a dataset is split into contiguous index ranges (the reference
+chunks its image list the same way over worker threads, image_space.py:3423-3425) and no pixel
+ever crosses xGMI.  The one exchange step is dataset exposure normalisation
+(``calculate_average_exposure``, image_space.py:4323-4398): every rank needs the brightness of
+ALL images to form the reference value, so the per-image brightness scalars are all-gathered
+(RCCL through ``torch.distributed``; 4 bytes per image, latency-bound).
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+
+def shard_range(n_images: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous balanced shard ``(first, count)`` of ``n_images`` for ``rank`` of ``world``."""
+    if world < 1 or not (0 <= rank < world) or n_images < 0:
+        raise ValueError(f"bad shard request: n={n_images} rank={rank} world={world}")
+    base, extra = divmod(n_images, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def gather_brightness(local, n_images: int, group=None):
+    """All-gather the per-image brightness of every rank's shard into one tensor in image order.
+
+    ``local`` is this rank's 1-D float32 tensor (``shard_range`` order), on the GPU (backend nccl =
+    RCCL) or on the CPU (backend gloo).  Uneven shards are padded to the largest shard for the
+    collective and compacted afterwards.  With a single process the input is returned as is.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if local.numel() != n_images:
+            raise ValueError("single-process gather needs the brightness of every image")
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    first, count = shard_range(n_images, rank, world)
+    if local.numel() != count:
+        raise ValueError(f"rank {rank} holds {local.numel()} values, its shard has {count}")
+    longest = shard_range(n_images, 0, world)[1]
+    if n_images % world == 0:
+        out = torch.empty((n_images,), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    padded = torch.zeros((longest,), dtype=local.dtype, device=local.device)
+    padded[:count] = local
+    buf = torch.empty((world * longest,), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    pieces = [buf[r * longest: r * longest + shard_range(n_images, r, world)[1]] for r in range(world)]
+    return torch.cat(pieces)
+
+
+class ExposureNormaliser:
+    """Device-side dataset exposure normalisation for one rank's shard.
+
+    ``run`` = per-thumbnail masked-luminance statistics (HIP) -> all-gather (RCCL, if more than one
+    rank) -> multipliers for the local shard (HIP), written to ``self.gains`` (device float32,
+    one per local image) which ``ss_chain_desc.gain0_dev`` consumes.
+    """
+
+    def __init__(self, ctx, n_images: int, rank: int = 0, world: int = 1, shadow_limit: float = 0.06,
+                 highlight_limit: float = 0.96, chart_index: Optional[int] = None, group=None):
+        import torch
+
+        self.ctx, self.n_images, self.rank, self.world, self.group = ctx, n_images, rank, world, group
+        self.first, self.count = shard_range(n_images, rank, world)
+        self.shadow_limit, self.highlight_limit, self.chart_index = shadow_limit, highlight_limit, chart_index
+        dev = torch.device("cuda", ctx.device)
+        self.brightness = torch.empty((self.count,), dtype=torch.float32, device=dev)
+        self.gains = torch.empty((self.count,), dtype=torch.float32, device=dev)
+        self.brightness_all = self.brightness
+
+    def run(self, thumbs_ptr: int, thumb_h: int, thumb_w: int):
+        self.ctx.exposure_stats(thumbs_ptr, thumb_h, thumb_w, self.count, self.shadow_limit, self.highlight_limit,
+                                None, self.brightness.data_ptr())
+        self.brightness_all = gather_brightness(self.brightness, self.n_images, self.group)
+        self.ctx.exposure_multipliers(self.brightness_all.data_ptr(), self.n_images, self.chart_index,
+                                      self.first, self.count, self.gains.data_ptr())
+        return self.gains

@@ -1,0 +1,204 @@
+"""Host-side logic and the C-ABI surface, without a GPU: the library loads, exports every symbol
+the header declares, its structs match the ctypes mirrors, and the pure-host entry points agree
+with the oracle.  No kernel is launched here."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import chain as oc
+from oracle import inputs
+from oracle import leaves as lv
+from scanspaceimageprocessor_amd import _lib
+from scanspaceimageprocessor_amd.chain import make_desc
+from scanspaceimageprocessor_amd.colour_fit import matrix_colour_correction
+from scanspaceimageprocessor_amd.dataset import shard_range
+from scanspaceimageprocessor_amd.ImageProcessor import editingTools as et
+from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as ipw
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "scanspace.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load_library()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/scanspace.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES out of sync with the header"
+    assert b"gfx950" in lib.ss_version()
+
+
+def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
+    fields = [f[0] for f in _lib.ChainDesc._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){',
+             'printf("%zu\\n", sizeof(ss_chain_desc));']
+    lines += [f'printf("%zu\\n", offsetof(ss_chain_desc, {f}));' for f in fields]
+    lines += ['printf("%zu\\n", sizeof(ss_percentile_detail));', 'printf("%zu\\n", sizeof(ss_host_opts));',
+              'return 0;}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == C.sizeof(_lib.ChainDesc)
+    for f, off in zip(fields, out[1:1 + len(fields)]):
+        assert getattr(_lib.ChainDesc, f).offset == off, f
+    assert out[-2] == C.sizeof(_lib.PercentileDetail)
+    assert out[-1] == C.sizeof(_lib.HostOpts)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    with pytest.raises(_lib.ScanSpaceError):
+        _lib.Context(0)
+    img = inputs.linear_image(1, 8, 8)
+    with pytest.raises(_lib.ScanSpaceError):
+        et.adjust_exposure(img, 1.0)
+    with pytest.raises(_lib.ScanSpaceError):
+        et.ensure_positive_if_negative(img, True)  # a missing device is not swallowed
+
+
+@pytest.mark.parametrize("legacy", [True, False])
+def test_percentile_rank_matches_numpy_index_arithmetic(legacy):
+    rng = np.random.default_rng(0)
+    ns = [1, 2, 3, 10, 1000, 296815, 269664, 357500, 16777217] + list(rng.integers(1, 5_000_000, 40))
+    for n in ns:
+        for frac in (0.0, 0.005, 0.05, 0.5, 0.995, 1.0, float(rng.random())):
+            lo, hi, g = _lib.percentile_rank(int(n), frac, legacy)
+            elo, ehi, eg = lv.percentile_ranks(int(n), frac * 100.0, legacy)
+            assert (lo, hi) == (elo, ehi), (n, frac)
+            assert g == float(eg), (n, frac)
+
+
+def test_sample_step_matches_reference_rule():
+    for h, w in [(1, 1), (96, 128), (1100, 1300), (4000, 6000), (5504, 8256), (499, 501), (500, 500), (1000, 1000)]:
+        assert _lib.negative_sample_step(h, w) == oc.negative_sample_step(h, w)
+    assert _lib.negative_sample_step(4000, 6000) == 9 and _lib.negative_sample_step(5504, 8256) == 13
+
+
+@pytest.mark.parametrize("method,kw", [("Cheung 2004", dict(terms=t)) for t in lv.CHEUNG_TERMS]
+                         + [("Finlayson 2015", dict(degree=d)) for d in (1, 2, 3, 4)])
+def test_ccm_fit_matches_oracle(method, kw):
+    M_T, M_R = inputs.synthetic_swatches()
+    ccm, kind, terms = matrix_colour_correction(M_T, M_R, method=method, **kw)
+    want = lv.matrix_colour_correction(M_T, M_R, method, **kw)
+    assert ccm.shape == want.shape == (3, terms)
+    np.testing.assert_allclose(ccm, want, rtol=1e-9, atol=1e-9)
+    assert kind == (_lib.SS_CCM_CHEUNG if method == "Cheung 2004" else _lib.SS_CCM_ROOTPOLY)
+
+
+def test_ccm_fit_rejects_bad_input():
+    M_T, M_R = inputs.synthetic_swatches()
+    with pytest.raises(ValueError):
+        matrix_colour_correction(M_T, M_R, terms=4)
+    with pytest.raises(ValueError):
+        matrix_colour_correction(M_T[:, :2], M_R)
+    with pytest.raises(ValueError):
+        matrix_colour_correction(M_T, M_R, method="Vandermonde")
+
+
+def test_make_desc_fills_the_descriptor():
+    M_T, M_R = inputs.synthetic_swatches()
+    d = make_desc(10, 20, 3, neg=([0.1, 0.2, 0.3], [2.0, 3.0, 4.0]), ccm=matrix_colour_correction(M_T, M_R),
+                  gains=[1.5, (1.0, 1.1, 1.2)], sh=(0.5, -0.5), usm=(50, 2.0), final_clip=True, out="u16")
+    assert (d.height, d.width, d.batch) == (10, 20, 3)
+    assert d.neg_enabled == 1 and d.neg_p_low[1] == np.float32(0.2) and d.neg_inv_denom[2] == 4.0
+    assert d.ccm_kind == _lib.SS_CCM_CHEUNG and d.ccm_terms == 3
+    assert d.n_gain_stages == 2 and list(d.gain[0]) == [1.5, 1.5, 1.5] and d.gain[1][2] == np.float32(1.2)
+    assert d.sh_enabled == 1 and d.sh_falloff_power == 7.0 and d.usm_enabled == 1 and d.usm_radius == 2.0
+    assert d.final_clip == 1 and d.out_kind == _lib.SS_OUT_U16_SRGB
+    with pytest.raises(ValueError):
+        make_desc(1, 1, gains=[1, 1, 1, 1])
+
+
+def test_white_balance_multipliers_known_answers():
+    assert et.calculate_white_balance_multipliers(5500, 5500) == pytest.approx((1.0, 1.0, 1.0))
+    warm = et.calculate_white_balance_multipliers(6500, 3000)  # towards a warmer white: red up, blue down
+    assert min(warm) == pytest.approx(1.0) and warm[0] > warm[1] > warm[2]
+    tint = et.calculate_white_balance_multipliers(5500, 5500, 50.0)
+    assert tint[1] / tint[0] == pytest.approx(1.05)
+    x, y = et._cct_to_xy_kang2002(6500.0)  # Planckian locus at 6500 K is (0.3135, 0.3237)
+    assert abs(x - 0.3135) < 5e-4 and abs(y - 0.3237) < 5e-4
+
+
+def test_adjustment_stage_translation_keeps_reference_prescaling_and_order():
+    kw = et.adjustment_stages(exposure=1.0, shadows=35.0, highlights=0.5, current_wb=5000, target_wb=6000,
+                              sharpen_amount=20.0)
+    assert len(kw["gains"]) == 2 and kw["gains"][1] == 2.0  # white balance first, then exposure
+    assert kw["sh"] == (35.0 / 70, 0.5 * 1.3, 7.0)
+    assert kw["usm"] == (20.0, 1.0, 0.0)
+    assert et.adjustment_stages() == dict(gains=[])
+    with pytest.raises(NotImplementedError):
+        et.adjustment_stages(denoise_strength=10)
+
+
+def test_worker_stage_selection_follows_the_reference():
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    w = ipw.ImageCorrectionWorker(["a.nef"], M_T, "/tmp", None, output_format=".tiff", tiff_bitdepth=16,
+                                  sharpen_amount=30.0, shadow_adj=14.0)
+    w.image_metadata_map = {"a.nef": {"average_exposure": "1.25"}, "b.nef": {"average_exposure": None}}
+    kw = w.chain_stages("a.nef")
+    assert kw["gains"] == [1.25] and kw["sh"] == (14.0 / 70, 0.0, 7.0) and kw["final_clip"]
+    assert "usm" not in kw  # chart mode never sharpens
+    assert w.chain_stages("b.nef")["gains"] == [1.0] and w.chain_stages("missing.nef")["gains"] == [1.0]
+    assert w._out_kind(".tiff") == _lib.SS_OUT_U16_SRGB and w._out_kind(".jpg") == _lib.SS_OUT_U8_SRGB
+    assert w._out_kind(".exr") == _lib.SS_OUT_F32_LINEAR
+    w2 = ipw.ImageCorrectionWorker(["a.nef"], M_T, "/tmp", None, use_chart=False, sharpen_amount=30.0,
+                                   exposure_adj=0.5)
+    kw2 = w2.chain_stages("a.nef")
+    assert "ccm" not in kw2 and kw2["usm"] == (30.0, 1.0, 0.0) and kw2["gains"] == [2.0 ** 0.5]
+
+
+def test_worker_reports_errors_and_continues(tmp_path):
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    sig = ipw.WorkerSignals()
+    events = []
+    sig.status.connect(lambda *a: events.append(a))
+    w = ipw.ImageCorrectionWorker(["bad1.nef", "bad2.nef"], M_T, str(tmp_path), sig)
+
+    def loader(path):
+        raise IOError("cannot decode " + path)
+
+    w.raw_loader = loader
+    w.run()
+    assert [e[1] for e in events] == ["started", "error", "started", "error"]
+
+
+def test_shard_range_partitions_contiguously():
+    for n in (0, 1, 7, 64, 1024, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_neutral_settings_need_no_gpu():
+    img = inputs.linear_image(1, 8, 8)
+    assert et.adjust_exposure(img, 0) is img
+    assert et.adjust_shadows_highlights_combined(img, 0, 0) is img
+    assert et.adjust_sharpen(img, 0) is img
+    assert et.adjust_white_balance(img, 5500, 5500, 0) is img
+    assert et.ensure_positive_if_negative(img, enabled=False) is img
+    out = et.apply_all_adjustments(img)
+    assert out is not img and np.array_equal(out, img)
+    g = et.GlobalAdjustments()
+    assert g.apply_to_image(img) is img and not g.has_adjustments()
