@@ -125,8 +125,12 @@ def main():
     out = torch.empty((B, H, W, 3), dtype=torch.int16, device=dev)  # uint16 payload
 
     ctx = Context(local_rank)
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)  # library kernels and the collective share torch's stream
+    # one dedicated stream carries the library's kernels, the collective and the timing events
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx.set_stream(stream.cuda_stream)
     norm = ExposureNormaliser(ctx, n_total, rank, world, SHADOW_LIMIT, HIGHLIGHT_LIMIT)
     gains = norm.gains
 

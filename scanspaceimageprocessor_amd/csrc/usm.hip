@@ -1,20 +1,26 @@
 // Fused correction chain WITH the unsharp mask (stage 5) for gfx950.
 //
-//   usm_kernel : a workgroup owns a 128 x TH pixel tile, recomputes stages 1-4 + Lab lightness for
-//                the tile plus a halo of `r` pixels into LDS, runs the separable Gaussian there (row
-//                pass into registers, written back in place, then the column pass), and finishes the
-//                pixel (mask logic, Lab -> sRGB, encoding, quantisation) without ever writing an
-//                intermediate plane to HBM.  Algorithmic traffic: 12 B/px in + output.
+// A 512-thread workgroup owns a 128 x 32 pixel tile.
+//   phase 1  every thread walks the tile plus its halo of r pixels (flat index, lanes along x, so
+//            each wave-instruction is a contiguous run of 12-byte pixels), runs stages 1-4 and the
+//            RGB -> Lab conversion, and leaves Ln = L/100 of every slot and (a, b) of the tile's own
+//            pixels in LDS.  Halo pixels are recomputed rather than exchanged: 1.5x the per-pixel
+//            front work at r = 6, no intermediate plane in HBM, no inter-workgroup dependency.
+//   phase 2  row pass of the separable Gaussian (cv2 filters rows first), 4 outputs per thread from a
+//            sliding register window fed by ds_read_b128, into a second LDS plane.
+//   phase 3  column pass for the tile's pixels (pairs, ds_read_b64), mask logic, Lab -> sRGB, final
+//            encoding, quantisation, one 12-byte store per lane for 16-bit output.
+// Algorithmic HBM traffic: 12 B/px in + 12 / 6 / 3 B/px out; halo re-reads are served by L2.
+// LDS per workgroup at r = 6: (44 x 140 + 44 x 128 + 32 x 128 x 2) x 4 B = 79,936 B -> two workgroups
+// (16 waves) per CU.
 
 #include "ss_internal.h"
 
 namespace ss {
 
-// ------------------------------------------------------------------------------------------------
-// fused unsharp mask
-// ------------------------------------------------------------------------------------------------
-
 constexpr int USM_TW = 128;  // tile width: 64 lanes x 2 adjacent pixels
+constexpr int USM_TH = 32;   // tile height
+constexpr int USM_NT = 512;  // threads per workgroup
 
 template <int OUT>
 __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int y, int x, const Px o0, const Px o1) {
@@ -57,169 +63,126 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
   }
 }
 
-// R_T: compile-time blur radius (3 <-> sigma 1, 6 <-> sigma 2), 0 = runtime radius P.usm_r.
-// TH : tile height; the workgroup has TH*8 threads = TH/8 waves, each wave owns 8 tile rows.
-template <int R_T, int OUT, int TH>
-__global__ __launch_bounds__(TH * 8) void usm_kernel(const ChainParams P, const float* __restrict__ src,
+// R_T : compile-time blur radius (3 <-> sigma 1, 6 <-> sigma 2), 0 = runtime radius P.usm_r.
+// CCMC: CCM_LIN3 for the reference's 3-term correction, CCM_RUNTIME for everything else.
+template <int R_T, int CCMC, int OUT>
+__global__ __launch_bounds__(USM_NT) void usm_kernel(const ChainParams P, const float* __restrict__ src,
                                                      void* __restrict__ dst) {
-  constexpr int TW = USM_TW;
-  constexpr int NT = TH * 8;
-  constexpr int NW = NT / 64;
-  constexpr int ROWS = 8;  // tile rows per wave
-  constexpr int RMAX = R_T ? R_T : SS_MAX_USM_RADIUS;
-  constexpr int P2_ITERS = ((TH + 2 * RMAX) * (TW / 4) + NT - 1) / NT;
+  constexpr int TW = USM_TW, TH = USM_TH, NT = USM_NT;
   extern __shared__ __attribute__((aligned(16))) float S[];
 
   const int r = R_T ? R_T : P.usm_r;
-  const int PWv = TW + 2 * r;      // valid LDS row width
-  const int PW = (PWv + 3) & ~3;   // row pitch (16-byte aligned rows)
+  const int PWv = TW + 2 * r;     // slots per LDS row that hold data
+  const int PW = (PWv + 3) & ~3;  // row pitch in floats (rows stay 16-byte aligned)
   const int PH = TH + 2 * r;
+  float* __restrict__ Lt = S;                  // [PH][PW]  Ln of tile + halo
+  float* __restrict__ Ht = Lt + PH * PW;       // [PH][TW]  row-filtered Ln
+  float* __restrict__ AB = Ht + PH * TW;       // [TH][TW][2] a, b of the tile's pixels
   const int W = P.width, H = P.height;
   const int img = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const ImgParams ip = load_img_params(P, img);
   const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * P.n_px * 3);
+  // tiles whose halo stays inside the image skip the border arithmetic
+  const bool interior = x0 >= r && y0 >= r && x0 + TW + r <= W && y0 + TH + r <= H;
 
-  // ---- phase 1a: tile pixels (pairs), keep Ln/a/b in registers, Ln also to LDS ----
-  float stL[ROWS][2], stA[ROWS][2], stB[ROWS][2];
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const int ly = wave + NW * i;
-    const int sy = reflect_coord(y0 + ly, H);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int sx = reflect_coord(x0 + 2 * lane + j, W);
-      const F3 v = s[(uint32_t)sy * W + sx];
-      const Px p = front<CCM_RUNTIME, true>(Px{v.x, v.y, v.z}, P, ip);
-      Lab q;
-      if (P.lab_io) {
-        q = Lab{p.r, p.g, p.b};
-      } else {
-        q = rgb_to_lab(p, P);
-      }
-      stL[i][j] = q.L * 0.01f;
-      stA[i][j] = q.a;
-      stB[i][j] = q.b;
+  // ---- phase 1: stages 1-4 + RGB -> Lab for the tile and its halo ----
+  const int n_slots = PH * PWv;
+  for (int idx = tid; idx < n_slots; idx += NT) {
+    const int ly = idx / PWv;
+    const int lx = idx - ly * PWv;
+    int sy = y0 - r + ly, sx = x0 - r + lx;
+    if (!interior) {
+      sy = reflect_coord(sy, H);
+      sx = reflect_coord(sx, W);
     }
-    float* row = S + (ly + r) * PW + r + 2 * lane;
-    row[0] = stL[i][0];
-    row[1] = stL[i][1];
-  }
-
-  // ---- phase 1b: halo ring, lightness only ----
-  {
-    const int n_tb = 2 * r * PWv;  // top + bottom bands, full width
-    const int n_ring = n_tb + TH * 2 * r;
-    for (int idx = tid; idx < n_ring; idx += NT) {
-      int ly, lx;
-      if (idx < n_tb) {
-        const int row = idx / PWv;
-        lx = idx - row * PWv;
-        ly = row < r ? row : row + TH;
-      } else {
-        const int j = idx - n_tb;
-        const int row = j / (2 * r);
-        const int c = j - row * (2 * r);
-        ly = r + row;
-        lx = c < r ? c : c + TW;
-      }
-      const int sy = reflect_coord(y0 - r + ly, H);
-      const int sx = reflect_coord(x0 - r + lx, W);
-      const F3 v = s[(uint32_t)sy * W + sx];
-      const Px p = front<CCM_RUNTIME, true>(Px{v.x, v.y, v.z}, P, ip);
-      const float Ln = P.lab_io ? p.r * 0.01f : fmaf(1.16f, rgb_to_fy(p, P), -0.16f);
-      S[ly * PW + lx] = Ln;
+    const F3 v = s[(uint32_t)sy * W + sx];
+    const Px p = front<CCMC, true>(Px{v.x, v.y, v.z}, P, ip);
+    Lab q;
+    if (P.lab_io) {
+      q = Lab{p.r, p.g, p.b};
+    } else {
+      q = rgb_to_lab(p, P);
+    }
+    Lt[ly * PW + lx] = q.L * 0.01f;
+    const int cy = ly - r, cx = lx - r;
+    if ((unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW) {
+      *reinterpret_cast<float2*>(AB + (cy * TW + cx) * 2) = make_float2(q.a, q.b);
     }
   }
   __syncthreads();
 
-  // ---- phase 2: row pass (cv2 runs the row filter first), results held in registers ----
-  float4 hreg[P2_ITERS];
+  // ---- phase 2: row pass ----
   const int n_items = PH * (TW / 4);
+  for (int item = tid; item < n_items; item += NT) {
+    const int row = item >> 5, q = item & 31;
+    const float* base = Lt + row * PW + 4 * q;
+    float4 acc;
+    if constexpr (R_T != 0) {
+      constexpr int NV = (4 + 2 * R_T + 3) / 4;
+      float v[NV * 4];
 #pragma unroll
-  for (int it = 0; it < P2_ITERS; ++it) {
-    const int item = tid + it * NT;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (item < n_items) {
-      const int row = item >> 5, q = item & 31;
-      const float* base = S + row * PW + 4 * q;
-      if constexpr (R_T != 0) {
-        constexpr int NV = (4 + 2 * R_T + 3) / 4;
-        float v[NV * 4];
+      for (int k = 0; k < NV; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(base + 4 * k);
+        v[4 * k + 0] = t.x;
+        v[4 * k + 1] = t.y;
+        v[4 * k + 2] = t.z;
+        v[4 * k + 3] = t.w;
+      }
+      acc = make_float4(v[0] * P.taps[0], v[1] * P.taps[0], v[2] * P.taps[0], v[3] * P.taps[0]);
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          const float4 t = *reinterpret_cast<const float4*>(base + 4 * k);
-          v[4 * k + 0] = t.x;
-          v[4 * k + 1] = t.y;
-          v[4 * k + 2] = t.z;
-          v[4 * k + 3] = t.w;
-        }
-        acc.x = v[0] * P.taps[0];
-        acc.y = v[1] * P.taps[0];
-        acc.z = v[2] * P.taps[0];
-        acc.w = v[3] * P.taps[0];
-#pragma unroll
-        for (int j = 1; j <= 2 * R_T; ++j) {
-          acc.x = fmaf(v[j + 0], P.taps[j], acc.x);
-          acc.y = fmaf(v[j + 1], P.taps[j], acc.y);
-          acc.z = fmaf(v[j + 2], P.taps[j], acc.z);
-          acc.w = fmaf(v[j + 3], P.taps[j], acc.w);
-        }
-      } else {
-        float w0 = base[0], w1 = base[1], w2 = base[2], w3 = base[3];
-        const float t0 = P.taps[0];
-        acc = make_float4(w0 * t0, w1 * t0, w2 * t0, w3 * t0);
-        for (int j = 1; j <= 2 * r; ++j) {
-          w0 = w1;
-          w1 = w2;
-          w2 = w3;
-          w3 = base[j + 3];
-          const float t = P.taps[j];
-          acc.x = fmaf(w0, t, acc.x);
-          acc.y = fmaf(w1, t, acc.y);
-          acc.z = fmaf(w2, t, acc.z);
-          acc.w = fmaf(w3, t, acc.w);
-        }
+      for (int j = 1; j <= 2 * R_T; ++j) {
+        acc.x = fmaf(v[j + 0], P.taps[j], acc.x);
+        acc.y = fmaf(v[j + 1], P.taps[j], acc.y);
+        acc.z = fmaf(v[j + 2], P.taps[j], acc.z);
+        acc.w = fmaf(v[j + 3], P.taps[j], acc.w);
+      }
+    } else {
+      float w0 = base[0], w1 = base[1], w2 = base[2], w3 = base[3];
+      const float t0 = P.taps[0];
+      acc = make_float4(w0 * t0, w1 * t0, w2 * t0, w3 * t0);
+      for (int j = 1; j <= 2 * r; ++j) {
+        w0 = w1;
+        w1 = w2;
+        w2 = w3;
+        w3 = base[j + 3];
+        const float t = P.taps[j];
+        acc.x = fmaf(w0, t, acc.x);
+        acc.y = fmaf(w1, t, acc.y);
+        acc.z = fmaf(w2, t, acc.z);
+        acc.w = fmaf(w3, t, acc.w);
       }
     }
-    hreg[it] = acc;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < P2_ITERS; ++it) {
-    const int item = tid + it * NT;
-    if (item < n_items) {
-      const int row = item >> 5, q = item & 31;
-      *reinterpret_cast<float4*>(S + row * PW + 4 * q) = hreg[it];
-    }
+    *reinterpret_cast<float4*>(Ht + row * TW + 4 * q) = acc;
   }
   __syncthreads();
 
-  // ---- phase 3: column pass for the owned pixels, mask logic, Lab -> sRGB, encode, store ----
+  // ---- phase 3: column pass, mask logic, Lab -> sRGB, encode, store ----
   char* d = reinterpret_cast<char*>(dst) + (size_t)img * P.n_px * 3 * OutTraits<OUT>::BYTES;
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const int ly = wave + NW * i;
-    const float* col = S + ly * PW + 2 * lane;
+  for (int pair = tid; pair < TH * TW / 2; pair += NT) {
+    const int ly = pair >> 6, px = (pair & 63) * 2;
+    const float* col = Ht + ly * TW + px;
     float2 t = *reinterpret_cast<const float2*>(col);
     float b0 = t.x * P.taps[0], b1 = t.y * P.taps[0];
     if constexpr (R_T != 0) {
 #pragma unroll
       for (int j = 1; j <= 2 * R_T; ++j) {
-        t = *reinterpret_cast<const float2*>(col + j * PW);
+        t = *reinterpret_cast<const float2*>(col + j * TW);
         b0 = fmaf(t.x, P.taps[j], b0);
         b1 = fmaf(t.y, P.taps[j], b1);
       }
     } else {
       for (int j = 1; j <= 2 * r; ++j) {
-        t = *reinterpret_cast<const float2*>(col + j * PW);
+        t = *reinterpret_cast<const float2*>(col + j * TW);
         b0 = fmaf(t.x, P.taps[j], b0);
         b1 = fmaf(t.y, P.taps[j], b1);
       }
     }
-    const Lab q0 = usm_on_lab(stL[i][0], stA[i][0], stB[i][0], b0, P);
-    const Lab q1 = usm_on_lab(stL[i][1], stA[i][1], stB[i][1], b1, P);
+    const float* lc = Lt + (ly + r) * PW + r + px;
+    const float4 ab = *reinterpret_cast<const float4*>(AB + (ly * TW + px) * 2);
+    const Lab q0 = usm_on_lab(lc[0], ab.x, ab.y, b0, P);
+    const Lab q1 = usm_on_lab(lc[1], ab.z, ab.w, b1, P);
     Px o0, o1;
     if (P.lab_io) {
       o0 = Px{q0.L, q0.a, q0.b};
@@ -228,58 +191,64 @@ __global__ __launch_bounds__(TH * 8) void usm_kernel(const ChainParams P, const 
       o0 = lab_to_rgb(q0, P);
       o1 = lab_to_rgb(q1, P);
     }
-    usm_store_pair<OUT>(d, W, H, y0 + ly, x0 + 2 * lane, finish<OUT>(o0, P), finish<OUT>(o1, P));
+    usm_store_pair<OUT>(d, W, H, y0 + ly, x0 + px, finish<OUT>(o0, P), finish<OUT>(o1, P));
   }
 }
 
-static int g_usm_tile_h = 32;  // set once from SS_USM_TH before the first launch (tuning knob)
+static size_t usm_lds_bytes(int r) {
+  const int PW = (USM_TW + 2 * r + 3) & ~3, PH = USM_TH + 2 * r;
+  return (size_t)(PH * PW + PH * USM_TW + USM_TH * USM_TW * 2) * sizeof(float);
+}
 
-template <int R_T, int TH>
-static hipError_t launch_usm_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                 hipStream_t st) {
-  const int r = P.usm_r;
-  const int PW = (USM_TW + 2 * r + 3) & ~3;
-  const size_t lds = (size_t)(TH + 2 * r) * PW * sizeof(float);
-  const dim3 grid((P.width + USM_TW - 1) / USM_TW, (P.height + TH - 1) / TH, batch);
-  const dim3 block(TH * 8);
-  switch (out_kind) {
-    case SS_OUT_F32_LINEAR:
-      hipLaunchKernelGGL((usm_kernel<R_T, SS_OUT_F32_LINEAR, TH>), grid, block, lds, st, P, src, dst);
-      break;
-    case SS_OUT_F32_SRGB:
-      hipLaunchKernelGGL((usm_kernel<R_T, SS_OUT_F32_SRGB, TH>), grid, block, lds, st, P, src, dst);
-      break;
-    case SS_OUT_U16_SRGB:
-      hipLaunchKernelGGL((usm_kernel<R_T, SS_OUT_U16_SRGB, TH>), grid, block, lds, st, P, src, dst);
-      break;
-    case SS_OUT_U8_SRGB:
-      hipLaunchKernelGGL((usm_kernel<R_T, SS_OUT_U8_SRGB, TH>), grid, block, lds, st, P, src, dst);
-      break;
-    case SS_OUT_U8_LINEAR:
-      hipLaunchKernelGGL((usm_kernel<R_T, SS_OUT_U8_LINEAR, TH>), grid, block, lds, st, P, src, dst);
-      break;
-    default:
-      return hipErrorInvalidValue;
+template <int R_T, int CCMC, int OUT>
+static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* src, void* dst, hipStream_t st) {
+  const size_t lds = usm_lds_bytes(P.usm_r);
+  auto kern = usm_kernel<R_T, CCMC, OUT>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // per instantiation; the attribute is sticky for the process
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
   }
+  const dim3 grid((P.width + USM_TW - 1) / USM_TW, (P.height + USM_TH - 1) / USM_TH, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(USM_NT), lds, st, P, src, dst);
   return hipGetLastError();
 }
 
-template <int TH>
-static hipError_t launch_usm_r(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                               hipStream_t st) {
-  if (P.usm_r == 3) return launch_usm_out<3, TH>(P, batch, out_kind, src, dst, st);
-  if (P.usm_r == 6) return launch_usm_out<6, TH>(P, batch, out_kind, src, dst, st);
-  return launch_usm_out<0, TH>(P, batch, out_kind, src, dst, st);
+template <int R_T, int CCMC>
+static hipError_t launch_usm_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
+                                 hipStream_t st) {
+  switch (out_kind) {
+    case SS_OUT_F32_LINEAR:
+      return launch_usm_one<R_T, CCMC, SS_OUT_F32_LINEAR>(P, batch, src, dst, st);
+    case SS_OUT_F32_SRGB:
+      return launch_usm_one<R_T, CCMC, SS_OUT_F32_SRGB>(P, batch, src, dst, st);
+    case SS_OUT_U16_SRGB:
+      return launch_usm_one<R_T, CCMC, SS_OUT_U16_SRGB>(P, batch, src, dst, st);
+    case SS_OUT_U8_SRGB:
+      return launch_usm_one<R_T, CCMC, SS_OUT_U8_SRGB>(P, batch, src, dst, st);
+    case SS_OUT_U8_LINEAR:
+      return launch_usm_one<R_T, CCMC, SS_OUT_U8_LINEAR>(P, batch, src, dst, st);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+template <int R_T>
+static hipError_t launch_usm_ccm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
+                                 hipStream_t st) {
+  if (P.ccm_kind != SS_CCM_NONE && P.ccm_terms == 3) return launch_usm_out<R_T, CCM_LIN3>(P, batch, out_kind, src, dst, st);
+  return launch_usm_out<R_T, CCM_RUNTIME>(P, batch, out_kind, src, dst, st);
 }
 
 hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {
-  static const int th = [] {
-    const char* e = getenv("SS_USM_TH");
-    return (e && atoi(e) == 64) ? 64 : g_usm_tile_h;
-  }();
   if (P.usm_r < 1 || P.usm_r > SS_MAX_USM_RADIUS) return hipErrorInvalidValue;
-  return th == 64 ? launch_usm_r<64>(P, batch, out_kind, src, dst, st)
-                  : launch_usm_r<32>(P, batch, out_kind, src, dst, st);
+  if (P.usm_r == 3) return launch_usm_ccm<3>(P, batch, out_kind, src, dst, st);
+  if (P.usm_r == 6) return launch_usm_ccm<6>(P, batch, out_kind, src, dst, st);
+  return launch_usm_ccm<0>(P, batch, out_kind, src, dst, st);
 }
 
 }  // namespace ss
