@@ -14,7 +14,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscanspace_hip.so")
+# SCANSPACE_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("SCANSPACE_LIB") or os.path.join(_HERE, "libscanspace_hip.so")
 
 SS_OK = 0
 SS_ERR_INVALID, SS_ERR_HIP, SS_ERR_NOMEM, SS_ERR_UNSUPPORTED = -1, -2, -3, -4

@@ -144,7 +144,13 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
   } else if (d->ccm_kind != SS_CCM_NONE) {
     return fail(c, SS_ERR_INVALID, "unknown ccm_kind %d", d->ccm_kind);
   }
-  if (d->ccm_kind != SS_CCM_NONE) memcpy(P->ccm, d->ccm, sizeof(float) * 3 * d->ccm_terms);
+  if (d->ccm_kind != SS_CCM_NONE) {
+    const int T = d->ccm_terms;
+    for (int t = 0; t < T; ++t)
+      for (int ch = 0; ch < 3; ++ch) P->ccm_full[t][ch] = d->ccm[ch * T + t];
+    if (T == 3) memcpy(P->ccm3, d->ccm, sizeof(float) * 9);
+    if (T > 3 && T <= 8) memcpy(P->ccm_small, d->ccm, sizeof(float) * 3 * T);
+  }
 
   if (d->n_gain_stages < 0 || d->n_gain_stages > SS_MAX_GAIN_STAGES)
     return fail(c, SS_ERR_INVALID, "n_gain_stages must be 0..%d", SS_MAX_GAIN_STAGES);
@@ -180,7 +186,7 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
       g[i] = exp(-(x * x) / (2.0 * s * s));
       sum += g[i];
     }
-    for (int i = 0; i < k; ++i) P->taps[i] = (float)(g[i] / sum);
+    for (int i = 0; i <= r; ++i) P->taps[i] = (float)(g[i] / sum);  // symmetric: tap i == tap k-1-i
     P->usm_amount_scaled = (float)((double)d->usm_amount / 50.0);
     P->usm_thr = (float)((double)d->usm_threshold / 100.0);
     P->usm_inv_thr = P->usm_thr > 0.0f ? (float)(100.0 / (double)d->usm_threshold) : 0.0f;

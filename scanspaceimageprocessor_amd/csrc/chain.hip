@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const f
                                                     void* __restrict__ dst) {
   constexpr int G = OutTraits<OUT>::G;
   constexpr int K = 4 / G;  // groups per lane per trip: 4 pixels in flight per lane
+  __shared__ float4 M[ccm_needs_table<CCMC> ? SS_MAX_CCM_TERMS : 1];
+  if constexpr (ccm_needs_table<CCMC>) {
+    stage_ccm(P, M, threadIdx.x, 256);
+    __syncthreads();
+  }
   const int img = blockIdx.y;
   const ImgParams ip = load_img_params(P, img);
   const uint32_t n = (uint32_t)P.n_px;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const f
         Px o[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-          o[j] = finish<OUT>(front<CCMC, SH>(Px{in[k][j].x, in[k][j].y, in[k][j].z}, P, ip), P);
+          o[j] = finish<OUT>(front<CCMC, SH>(Px{in[k][j].x, in[k][j].y, in[k][j].z}, P, ip, M), P);
         }
         if constexpr (G == 1) {
           reinterpret_cast<F3*>(d)[g] = F3{o[0].r, o[0].g, o[0].b};
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const f
     const uint32_t px = n_groups * G + threadIdx.x;
     if (px < n) {
       const F3 v = s[px];
-      store_one<OUT>(d, px, finish<OUT>(front<CCMC, SH>(Px{v.x, v.y, v.z}, P, ip), P));
+      store_one<OUT>(d, px, finish<OUT>(front<CCMC, SH>(Px{v.x, v.y, v.z}, P, ip, M), P));
     }
   }
 }
@@ -134,6 +139,7 @@ static hipError_t launch_chain_sh(const ChainParams& P, int batch, int out_kind,
 hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {
   if (P.ccm_kind == SS_CCM_NONE) return launch_chain_sh<CCM_NONE>(P, batch, out_kind, src, dst, st);
   if (P.ccm_terms == 3) return launch_chain_sh<CCM_LIN3>(P, batch, out_kind, src, dst, st);
+  if (P.ccm_terms <= 8) return launch_chain_sh<CCM_SMALL>(P, batch, out_kind, src, dst, st);
   if (P.ccm_kind == SS_CCM_CHEUNG) return launch_chain_sh<CCM_CHEUNG>(P, batch, out_kind, src, dst, st);
   return launch_chain_sh<CCM_ROOT>(P, batch, out_kind, src, dst, st);
 }

@@ -22,7 +22,8 @@ struct ChainParams {
   const float* neg_dev;  // [batch][8]
 
   int32_t ccm_kind, ccm_terms;
-  float ccm[3 * SS_MAX_CCM_TERMS];
+  float ccm3[9];  // the 3-term matrix (the reference's only call form), read straight from SGPRs
+  float ccm_small[3 * 8];  // row-major 3 x T for 3 < T <= 8 (Cheung 5/7/8, root-polynomial degree 2), also SGPRs
 
   int32_t n_gain;
   float gain[SS_MAX_GAIN_STAGES][3];
@@ -40,7 +41,7 @@ struct ChainParams {
   float usm_inv_thr;        // 1 / usm_thr (0 when usm_thr == 0)
   int32_t usm_chroma;       // amount > 30
   float usm_chroma_k;       // amount / 100 * 0.1
-  float taps[2 * SS_MAX_USM_RADIUS + 1];
+  float taps[SS_MAX_USM_RADIUS + 1];  // taps[0..r]: the Gaussian is symmetric, tap j == tap 2r-j
 
   int32_t lab_io;
   int32_t final_clip;
@@ -48,7 +49,17 @@ struct ChainParams {
   // sRGB -> XYZ rows pre-divided by the D65 white, and XYZ -> sRGB columns pre-multiplied by it
   float m_fwd[9];
   float m_inv[9];
+
+  // Full 3 x T table for T > 3, as [t] = {row R, row G, row B, 0}.  Kept LAST and only ever read with a
+  // runtime index (staged into LDS at kernel start) so that it never occupies scalar registers.
+  float ccm_full[SS_MAX_CCM_TERMS][4];
 };
+
+// symmetric tap lookup with a compile-time index
+template <int R>
+__device__ __forceinline__ float tap_at(const ChainParams& P, int j) {
+  return P.taps[j <= R ? j : 2 * R - j];
+}
 
 struct Px {
   float r, g, b;
@@ -134,108 +145,159 @@ __device__ __forceinline__ Px lab_to_rgb(const Lab q, const ChainParams& P) {
 
 // ---- colour correction ---------------------------------------------------------------------
 
+// dot product of T expansion terms with the staged table M[t] = {cR, cG, cB, 0} (LDS, broadcast reads)
 template <int T>
-__device__ __forceinline__ Px ccm_dot(const float (&e)[T], const float* __restrict__ M) {
+__device__ __forceinline__ Px ccm_dot(const float (&e)[T], const float4* __restrict__ M) {
+  float4 c = M[0];
   Px o;
-  o.r = e[0] * M[0];
-  o.g = e[0] * M[T];
-  o.b = e[0] * M[2 * T];
+  o.r = e[0] * c.x;
+  o.g = e[0] * c.y;
+  o.b = e[0] * c.z;
 #pragma unroll
   for (int t = 1; t < T; ++t) {
-    o.r = fmaf(e[t], M[t], o.r);
-    o.g = fmaf(e[t], M[T + t], o.g);
-    o.b = fmaf(e[t], M[2 * T + t], o.b);
+    c = M[t];
+    o.r = fmaf(e[t], c.x, o.r);
+    o.g = fmaf(e[t], c.y, o.g);
+    o.b = fmaf(e[t], c.z, o.b);
   }
   return o;
 }
 
 __device__ __forceinline__ Px ccm_linear3(const Px p, const ChainParams& P) {
-  const float e[3] = {p.r, p.g, p.b};
-  return ccm_dot<3>(e, P.ccm);
+  Px o;
+  o.r = fmaf(P.ccm3[2], p.b, fmaf(P.ccm3[1], p.g, P.ccm3[0] * p.r));
+  o.g = fmaf(P.ccm3[5], p.b, fmaf(P.ccm3[4], p.g, P.ccm3[3] * p.r));
+  o.b = fmaf(P.ccm3[8], p.b, fmaf(P.ccm3[7], p.g, P.ccm3[6] * p.r));
+  return o;
 }
 
-// colour.characterisation.matrix_augmented_Cheung2004 term lists
-__device__ __forceinline__ Px ccm_cheung(const Px p, const ChainParams& P) {
+// dot product with a small table held in scalar registers (row-major 3 x T, compile-time indices)
+template <int T>
+__device__ __forceinline__ Px ccm_dot_small(const float (&e)[T], const ChainParams& P) {
+  Px o;
+  o.r = e[0] * P.ccm_small[0];
+  o.g = e[0] * P.ccm_small[T];
+  o.b = e[0] * P.ccm_small[2 * T];
+#pragma unroll
+  for (int t = 1; t < T; ++t) {
+    o.r = fmaf(e[t], P.ccm_small[t], o.r);
+    o.g = fmaf(e[t], P.ccm_small[T + t], o.g);
+    o.b = fmaf(e[t], P.ccm_small[2 * T + t], o.b);
+  }
+  return o;
+}
+
+// 3 < T <= 8: Cheung 2004 with 5, 7 or 8 terms, Finlayson 2015 root-polynomial of degree 2 (6 terms)
+__device__ __forceinline__ Px ccm_small_terms(const Px p, const ChainParams& P) {
   const float R = p.r, G = p.g, B = p.b;
   switch (P.ccm_terms) {
-    case 3: {
-      const float e[3] = {R, G, B};
-      return ccm_dot<3>(e, P.ccm);
-    }
     case 5: {
       const float e[5] = {R, G, B, R * G * B, 1.0f};
-      return ccm_dot<5>(e, P.ccm);
+      return ccm_dot_small<5>(e, P);
+    }
+    case 6: {
+      const float e[6] = {R, G, B, sroot2(R * G), sroot2(G * B), sroot2(R * B)};
+      return ccm_dot_small<6>(e, P);
     }
     case 7: {
       const float e[7] = {R, G, B, R * G, R * B, G * B, 1.0f};
-      return ccm_dot<7>(e, P.ccm);
+      return ccm_dot_small<7>(e, P);
+    }
+    default: {  // 8
+      const float e[8] = {R, G, B, R * G, R * B, G * B, R * G * B, 1.0f};
+      return ccm_dot_small<8>(e, P);
+    }
+  }
+}
+
+// Cooperative copy of the full table into LDS; callers synchronise the workgroup afterwards.
+__device__ __forceinline__ void stage_ccm(const ChainParams& P, float4* __restrict__ M, int tid, int nthreads) {
+  for (int t = tid; t < P.ccm_terms; t += nthreads)
+    M[t] = make_float4(P.ccm_full[t][0], P.ccm_full[t][1], P.ccm_full[t][2], 0.0f);
+}
+
+// colour.characterisation.matrix_augmented_Cheung2004 term lists
+__device__ __forceinline__ Px ccm_cheung(const Px p, const int terms, const float4* __restrict__ M) {
+  const float R = p.r, G = p.g, B = p.b;
+  switch (terms) {
+    case 3: {
+      const float e[3] = {R, G, B};
+      return ccm_dot<3>(e, M);
+    }
+    case 5: {
+      const float e[5] = {R, G, B, R * G * B, 1.0f};
+      return ccm_dot<5>(e, M);
+    }
+    case 7: {
+      const float e[7] = {R, G, B, R * G, R * B, G * B, 1.0f};
+      return ccm_dot<7>(e, M);
     }
     case 8: {
       const float e[8] = {R, G, B, R * G, R * B, G * B, R * G * B, 1.0f};
-      return ccm_dot<8>(e, P.ccm);
+      return ccm_dot<8>(e, M);
     }
     case 10: {
       const float e[10] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, 1.0f};
-      return ccm_dot<10>(e, P.ccm);
+      return ccm_dot<10>(e, M);
     }
     case 11: {
       const float e[11] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B, 1.0f};
-      return ccm_dot<11>(e, P.ccm);
+      return ccm_dot<11>(e, M);
     }
     case 14: {
       const float e[14] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
                            R * R * R, G * G * G, B * B * B, 1.0f};
-      return ccm_dot<14>(e, P.ccm);
+      return ccm_dot<14>(e, M);
     }
     case 16: {
       const float e[16] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
                            R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B};
-      return ccm_dot<16>(e, P.ccm);
+      return ccm_dot<16>(e, M);
     }
     case 17: {
       const float e[17] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
                            R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B, 1.0f};
-      return ccm_dot<17>(e, P.ccm);
+      return ccm_dot<17>(e, M);
     }
     case 19: {
       const float e[19] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
                            R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
                            R * R * R, G * G * G, B * B * B};
-      return ccm_dot<19>(e, P.ccm);
+      return ccm_dot<19>(e, M);
     }
     case 20: {
       const float e[20] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
                            R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
                            R * R * R, G * G * G, B * B * B, 1.0f};
-      return ccm_dot<20>(e, P.ccm);
+      return ccm_dot<20>(e, M);
     }
     default: {  // 22
       const float e[22] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
                            R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
                            R * R * R, G * G * G, B * B * B, R * R * G * B, R * G * G * B, R * G * B * B};
-      return ccm_dot<22>(e, P.ccm);
+      return ccm_dot<22>(e, M);
     }
   }
 }
 
 // colour.characterisation.polynomial_expansion_Finlayson2015(root_polynomial_expansion=True)
-__device__ __forceinline__ Px ccm_rootpoly(const Px p, const ChainParams& P) {
+__device__ __forceinline__ Px ccm_rootpoly(const Px p, const int terms, const float4* __restrict__ M) {
   const float R = p.r, G = p.g, B = p.b;
   const float rg = R * G, gb = G * B, rb = R * B;
-  switch (P.ccm_terms) {
+  switch (terms) {
     case 3: {
       const float e[3] = {R, G, B};
-      return ccm_dot<3>(e, P.ccm);
+      return ccm_dot<3>(e, M);
     }
     case 6: {
       const float e[6] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb)};
-      return ccm_dot<6>(e, P.ccm);
+      return ccm_dot<6>(e, M);
     }
     case 13: {
       const float e[13] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
                            sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
                            sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B)};
-      return ccm_dot<13>(e, P.ccm);
+      return ccm_dot<13>(e, M);
     }
     default: {  // 22
       const float e[22] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
@@ -244,29 +306,35 @@ __device__ __forceinline__ Px ccm_rootpoly(const Px p, const ChainParams& P) {
                            sroot4(R * R * rg), sroot4(R * R * rb), sroot4(G * G * rg),
                            sroot4(G * G * gb), sroot4(B * B * rb), sroot4(B * B * gb),
                            sroot4(R * rg * B), sroot4(G * rg * B), sroot4(B * rb * G)};
-      return ccm_dot<22>(e, P.ccm);
+      return ccm_dot<22>(e, M);
     }
   }
 }
 
-enum CcmClass { CCM_NONE = 0, CCM_LIN3 = 1, CCM_CHEUNG = 2, CCM_ROOT = 3, CCM_RUNTIME = 4 };
+enum CcmClass { CCM_NONE = 0, CCM_LIN3 = 1, CCM_CHEUNG = 2, CCM_ROOT = 3, CCM_RUNTIME = 4, CCM_SMALL = 5 };
 
 template <int CCMC>
-__device__ __forceinline__ Px apply_ccm(const Px p, const ChainParams& P) {
+__device__ __forceinline__ Px apply_ccm(const Px p, const ChainParams& P, const float4* __restrict__ M) {
   if constexpr (CCMC == CCM_NONE) {
     return p;
   } else if constexpr (CCMC == CCM_LIN3) {
     return ccm_linear3(p, P);
+  } else if constexpr (CCMC == CCM_SMALL) {
+    return ccm_small_terms(p, P);
   } else if constexpr (CCMC == CCM_CHEUNG) {
-    return ccm_cheung(p, P);
+    return ccm_cheung(p, P.ccm_terms, M);
   } else if constexpr (CCMC == CCM_ROOT) {
-    return ccm_rootpoly(p, P);
+    return ccm_rootpoly(p, P.ccm_terms, M);
   } else {
     if (P.ccm_kind == SS_CCM_NONE) return p;
-    if (P.ccm_kind == SS_CCM_CHEUNG) return P.ccm_terms == 3 ? ccm_linear3(p, P) : ccm_cheung(p, P);
-    return ccm_rootpoly(p, P);
+    if (P.ccm_kind == SS_CCM_CHEUNG) return ccm_cheung(p, P.ccm_terms, M);
+    return ccm_rootpoly(p, P.ccm_terms, M);
   }
 }
+
+// kernels of these classes stage the full table into LDS
+template <int CCMC>
+constexpr bool ccm_needs_table = (CCMC == CCM_CHEUNG || CCMC == CCM_ROOT || CCMC == CCM_RUNTIME);
 
 // ---- per-image parameters -------------------------------------------------------------------
 
@@ -304,14 +372,23 @@ __device__ __forceinline__ Lab sh_on_lab(Lab q, const ChainParams& P) {
 
 // ---- stages 1-4 on one pixel -----------------------------------------------------------------
 
-template <int CCMC, bool SH>
-__device__ __forceinline__ Px front(Px p, const ChainParams& P, const ImgParams& ip) {
+// PLAIN = the caller guarantees: no negative inversion, exactly one gain stage, no shadows/highlights,
+// RGB data.  Everything else about a chain is then dead code and its parameters never reach registers.
+template <int CCMC, bool SH, bool PLAIN = false>
+__device__ __forceinline__ Px front(Px p, const ChainParams& P, const ImgParams& ip, const float4* __restrict__ M) {
+  if constexpr (PLAIN) {
+    p = apply_ccm<CCMC>(p, P, M);
+    p.r = clamp01(p.r * ip.gain0[0]);
+    p.g = clamp01(p.g * ip.gain0[1]);
+    p.b = clamp01(p.b * ip.gain0[2]);
+    return p;
+  }
   if (P.neg) {
     p.r = 1.0f - clamp01((clamp01(p.r) - ip.neg_lo[0]) * ip.neg_inv[0]);
     p.g = 1.0f - clamp01((clamp01(p.g) - ip.neg_lo[1]) * ip.neg_inv[1]);
     p.b = 1.0f - clamp01((clamp01(p.b) - ip.neg_lo[2]) * ip.neg_inv[2]);
   }
-  p = apply_ccm<CCMC>(p, P);
+  p = apply_ccm<CCMC>(p, P, M);
   if (P.n_gain > 0) {
     p.r = clamp01(p.r * ip.gain0[0]);
     p.g = clamp01(p.g * ip.gain0[1]);
@@ -342,10 +419,11 @@ __device__ __forceinline__ Px front(Px p, const ChainParams& P, const ImgParams&
 
 // ---- stage 5 pointwise part: unsharp mask on (Ln, blurred Ln) (editingTools.py:767-809) -------
 
+template <bool PLAIN = false>
 __device__ __forceinline__ Lab usm_on_lab(const float Ln, const float a, const float b, const float Lb,
                                           const ChainParams& P) {
   float um = Ln - Lb;
-  if (P.usm_thr > 0.0f) {
+  if (!PLAIN && P.usm_thr > 0.0f) {
     const float es = fabsf(um);
     um *= es > P.usm_thr ? 1.0f : es * P.usm_inv_thr;
   }
@@ -367,9 +445,9 @@ __device__ __forceinline__ Lab usm_on_lab(const float Ln, const float a, const f
 
 // ---- stages 6-7: final clip, encoding, quantisation -------------------------------------------
 
-template <int OUT>
+template <int OUT, bool IN_RANGE = false>
 __device__ __forceinline__ Px finish(Px p, const ChainParams& P) {
-  if (P.final_clip) {
+  if (!IN_RANGE && P.final_clip) {
     p.r = clamp01(p.r);
     p.g = clamp01(p.g);
     p.b = clamp01(p.b);

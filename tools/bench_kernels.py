@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Kernel-level timings of the BASELINE.json configurations on one GPU (HIP events on the library's
+stream, inputs resident in HBM).  Prints one line per configuration: ms per launch, MP/s and the
+algorithmic-bytes rate against the 8 TB/s HBM peak.
+
+  python tools/bench_kernels.py [--batch 8] [--reps 5] [--configs 1,2,2b,3,4,4b,5s]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from scanspaceimageprocessor_amd import Context, _lib  # noqa: E402
+from scanspaceimageprocessor_amd.chain import make_desc  # noqa: E402
+from scanspaceimageprocessor_amd.colour_fit import matrix_colour_correction  # noqa: E402
+
+
+def swatches():
+    r = np.random.default_rng(7)
+    M_R = 0.03 + 0.87 * r.random((24, 3))
+    c = np.random.default_rng(8)
+    A = np.eye(3) + 0.15 * (c.random((3, 3)) * 2.0 - 1.0)
+    return (M_R @ A.T + c.normal(0.0, 0.002, size=(24, 3))).astype(np.float32), M_R
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--configs", default="1,2,2b,3,4,4b")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    ctx = Context(0)
+    M_T, M_R = swatches()
+    lin3 = matrix_colour_correction(M_T, M_R)
+
+    def images(h, w, b, negative=False):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234)
+        x = torch.rand((b, h, w, 3), generator=g, device=dev, dtype=torch.float32).pow_(2.2).mul_(0.9)
+        if negative:
+            x = 0.08 + 0.8 * (1.0 - x) * torch.tensor([1.0, 0.75, 0.55], device=dev)
+        return x.contiguous()
+
+    def timeit(fn):
+        fn()
+        ctx.sync()
+        ts = []
+        for _ in range(args.reps):
+            ctx.timer_start()
+            fn()
+            ts.append(ctx.timer_stop())
+        return float(np.median(ts)), float(np.min(ts))
+
+    def report(name, h, w, b, bytes_px, ms, ms_min):
+        mp = b * h * w / 1e6
+        gbs = bytes_px * b * h * w / (ms * 1e-3) / 1e9
+        print(f"{name:34s} {b}x{h}x{w}  {ms:8.3f} ms (min {ms_min:8.3f})  {mp / (ms * 1e-3):10.0f} MP/s  "
+              f"{gbs:7.0f} GB/s algorithmic = {gbs / 8000:.3f} of HBM peak", flush=True)
+
+    todo = args.configs.split(",")
+    H, W, B = 4000, 6000, args.batch
+    if any(c in todo for c in ("1", "2", "2b", "3", "1u16", "1u8")):
+        img = images(H, W, B)
+        out = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+    if "1" in todo:
+        d = make_desc(H, W, B, ccm=lin3, gains=[1.0], out="f32_srgb")
+        report("1  ccm3+clip+srgb f32", H, W, B, 24, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "1u16" in todo:
+        d = make_desc(H, W, B, ccm=lin3, gains=[1.0], out="u16")
+        report("1u16 ccm3+clip+srgb u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "1u8" in todo:
+        d = make_desc(H, W, B, ccm=lin3, gains=[1.0], out="u8")
+        report("1u8 ccm3+clip+srgb u8", H, W, B, 15, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "2" in todo:
+        d = make_desc(H, W, B, ccm=lin3, gains=[1.1], usm=(1.0, 2.0, 0.0), final_clip=True, out="u16")
+        report("2  ccm3+gain+usm(r2,a1)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "2b" in todo:
+        d = make_desc(H, W, B, ccm=lin3, gains=[1.1], usm=(50.0, 2.0, 0.0), final_clip=True, out="u16")
+        report("2b ccm3+gain+usm(r2,a50)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "2r1" in todo:
+        d = make_desc(H, W, B, ccm=lin3, gains=[1.1], usm=(50.0, 1.0, 0.0), final_clip=True, out="u16")
+        report("2r1 ccm3+gain+usm(r1,a50)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "3" in todo:
+        neg = images(H, W, B, negative=True)
+        params = torch.empty((B, _lib.SS_NEG_PARAM_STRIDE), dtype=torch.float32, device=dev)
+        d = make_desc(H, W, B, neg=True, neg_params_dev=params.data_ptr(), ccm=lin3, out="f32")
+
+        def run3():
+            ctx.negative_params(neg.data_ptr(), H, W, B, 0.005, 0.995, True, params.data_ptr())
+            ctx.chain_run(d, neg.data_ptr(), out.data_ptr())
+
+        report("3  percentiles+invert+ccm3 f32", H, W, B, 24.15, *timeit(run3))
+        report("3p percentiles only", H, W, B, 12.0 / 81,
+               *timeit(lambda: ctx.negative_params(neg.data_ptr(), H, W, B, 0.005, 0.995, True, params.data_ptr())))
+        del neg
+    if "4" in todo or "4b" in todo:
+        H4, W4, B4 = 5504, 8256, max(1, args.batch // 2)
+        img4 = images(H4, W4, B4)
+        out4 = torch.empty_like(img4)
+        for name, deg in (("4", 2), ("4b", 3)):
+            if name in todo:
+                ccm = matrix_colour_correction(M_T, M_R, method="Finlayson 2015", degree=deg)
+                d = make_desc(H4, W4, B4, ccm=ccm, gains=[1.0], sh=(0.5, -0.5, 7.0), final_clip=True, out="f32")
+                report(f"{name:2s} rootpoly(d{deg})+clip+S/H f32", H4, W4, B4, 24,
+                       *timeit(lambda: ctx.chain_run(d, img4.data_ptr(), out4.data_ptr())))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build a tuning variant of libscanspace_hip.so: tools/build_variant.sh NAME [extra hipcc flags...]
+# -> scanspaceimageprocessor_amd/variants/libscanspace_hip.NAME.so  (select it with SCANSPACE_LIB=...)
+set -e
+cd "$(dirname "$0")/../scanspaceimageprocessor_amd/csrc"
+name=$1; shift
+mkdir -p ../variants build/$name
+for f in chain usm stats api; do
+  if [ "$f" = usm ] || [ ! -f build/$f.o ]; then
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value "$@" -c $f.hip -o build/$name/$f.o &
+  else
+    cp build/$f.o build/$name/$f.o
+  fi
+done
+wait
+hipcc -shared -fPIC --offload-arch=gfx950 -o ../variants/libscanspace_hip.$name.so build/$name/*.o
+echo built ../variants/libscanspace_hip.$name.so
