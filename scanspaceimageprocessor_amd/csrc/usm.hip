@@ -20,7 +20,11 @@ namespace ss {
 
 constexpr int USM_TW = 128;  // tile width: 64 lanes x 2 adjacent pixels
 constexpr int USM_TH = 32;   // tile height
-constexpr int USM_NT = 512;  // threads per workgroup
+#ifndef SS_USM_NT
+#define SS_USM_NT 512
+#endif
+constexpr int USM_NT = SS_USM_NT;  // threads per workgroup
+constexpr int USM_WAVES_PER_SIMD = 2 * USM_NT / 256;  // two workgroups per CU
 
 #ifndef SS_USM_PREFETCH
 #define SS_USM_PREFETCH 13  // phase-1 pixels in flight per thread (13 = the whole tile at r = 6)
@@ -79,7 +83,7 @@ struct TileWalk {
 };
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>
-__global__ __launch_bounds__(USM_NT, 4) void usm_kernel(const ChainParams P, const TileWalk T,
+__global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const TileWalk T,
                                                      const float* __restrict__ src, void* __restrict__ dst) {
   constexpr int TW = USM_TW, TH = USM_TH, NT = USM_NT;
   extern __shared__ __attribute__((aligned(16))) float S[];
