@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const f
   constexpr uint32_t CHUNK = 256 * K;
 
   for (uint32_t base = blockIdx.x * CHUNK; base < n_groups; base += gridDim.x * CHUNK) {
-    F3 in[K][G];
+    F3 in[K][G] = {};
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t g = base + k * 256 + threadIdx.x;
@@ -59,15 +59,25 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const f
         for (int j = 0; j < G; ++j) in[k][j] = s[g * G + j];
       }
     }
+    // the K*G = 4 pixels of this lane go through the stages as two packed pairs (lanes past the end of the
+    // image compute on stale registers and store nothing)
+    Px flat[K * G];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < G; ++j) flat[k * G + j] = Px{in[k][j].x, in[k][j].y, in[k][j].z};
+    Px res[K * G];
+#pragma unroll
+    for (int q = 0; q < K * G; q += 2) {
+      const Px2 o2 = finish<OUT, false, v2f>(front<CCMC, SH, false, v2f>(pair_px(flat[q], flat[q + 1]), P, ip, M), P);
+      res[q] = px_lo(o2);
+      res[q + 1] = px_hi(o2);
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t g = base + k * 256 + threadIdx.x;
       if (g < n_groups) {
-        Px o[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          o[j] = finish<OUT>(front<CCMC, SH>(Px{in[k][j].x, in[k][j].y, in[k][j].z}, P, ip, M), P);
-        }
+        const Px* o = res + k * G;
         if constexpr (G == 1) {
           reinterpret_cast<F3*>(d)[g] = F3{o[0].r, o[0].g, o[0].b};
         } else if constexpr (G == 2) {
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const f
     const uint32_t px = n_groups * G + threadIdx.x;
     if (px < n) {
       const F3 v = s[px];
-      store_one<OUT>(d, px, finish<OUT>(front<CCMC, SH>(Px{v.x, v.y, v.z}, P, ip, M), P));
+      store_one<OUT>(d, px, finish<OUT, false, float>(front<CCMC, SH, false, float>(Px{v.x, v.y, v.z}, P, ip, M), P));
     }
   }
 }

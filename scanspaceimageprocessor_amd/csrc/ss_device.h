@@ -61,151 +61,191 @@ __device__ __forceinline__ float tap_at(const ChainParams& P, int j) {
   return P.taps[j <= R ? j : 2 * R - j];
 }
 
-struct Px {
-  float r, g, b;
-};
-struct Lab {
-  float L, a, b;
-};
+// ---- value types ----------------------------------------------------------------------------
+// Every stage is written once for V = float (one pixel per lane) and V = v2f (two pixels per lane in
+// lock step).  On gfx950 a plain VALU instruction issues in ~4 cycles per wave64 while the packed
+// v_pk_mul/add/fma_f32 forms do two lanes' worth of work in ~5, so the pair form cuts the cost of all
+// multiply/add/fma work by about a third; comparisons, selects, clamps and transcendentals stay per element.
 
-// ---- scalar helpers -----------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <class V>
+struct PxT {
+  V r, g, b;
+};
+template <class V>
+struct LabT {
+  V L, a, b;
+};
+using Px = PxT<float>;
+using Lab = LabT<float>;
+using Px2 = PxT<v2f>;
+using Lab2 = LabT<v2f>;
+
+__device__ __forceinline__ Px2 pair_px(const Px a, const Px b) { return Px2{v2f{a.r, b.r}, v2f{a.g, b.g}, v2f{a.b, b.b}}; }
+__device__ __forceinline__ Px px_lo(const Px2 p) { return Px{p.r.x, p.g.x, p.b.x}; }
+__device__ __forceinline__ Px px_hi(const Px2 p) { return Px{p.r.y, p.g.y, p.b.y}; }
+
+// a * b + c with any mix of V and float operands (floats are splatted)
+template <class V, class A, class B, class C>
+__device__ __forceinline__ V mad(A a, B b, C c) {
+  return __builtin_elementwise_fma((V)(a), (V)(b), (V)(c));
+}
+
+// ---- per-element helpers ----------------------------------------------------------------------
 
 __device__ __forceinline__ float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ float vabs(float x) { return fabsf(x); }
+__device__ __forceinline__ float vcopysign(float m, float s) { return copysignf(m, s); }
 
-// x ** p for x > 0 (callers select the linear segment for everything else)
-__device__ __forceinline__ float pow_pos(float x, float p) { return hw_exp2(hw_log2(x) * p); }
+__device__ __forceinline__ v2f hw_log2(v2f x) { return v2f{hw_log2(x.x), hw_log2(x.y)}; }
+__device__ __forceinline__ v2f hw_exp2(v2f x) { return v2f{hw_exp2(x.x), hw_exp2(x.y)}; }
+__device__ __forceinline__ v2f hw_sqrt(v2f x) { return v2f{hw_sqrt(x.x), hw_sqrt(x.y)}; }
+__device__ __forceinline__ v2f clamp01(v2f x) { return v2f{clamp01(x.x), clamp01(x.y)}; }
+__device__ __forceinline__ v2f clampf(v2f x, float lo, float hi) { return v2f{clampf(x.x, lo, hi), clampf(x.y, lo, hi)}; }
+__device__ __forceinline__ v2f vabs(v2f x) { return v2f{fabsf(x.x), fabsf(x.y)}; }
+__device__ __forceinline__ v2f vcopysign(v2f m, v2f s) { return v2f{copysignf(m.x, s.x), copysignf(m.y, s.y)}; }
 
 // colour.algebra.spow with p = 1/2, 1/3, 1/4: sign(x) * |x| ** p, exact zero at zero
-__device__ __forceinline__ float sroot2(float x) { return copysignf(hw_sqrt(fabsf(x)), x); }
-__device__ __forceinline__ float sroot3(float x) { return copysignf(hw_exp2(hw_log2(fabsf(x)) * (1.0f / 3.0f)), x); }
-__device__ __forceinline__ float sroot4(float x) { return copysignf(hw_sqrt(hw_sqrt(fabsf(x))), x); }
+template <class V>
+__device__ __forceinline__ V sroot2(V x) { return vcopysign(hw_sqrt(vabs(x)), x); }
+template <class V>
+__device__ __forceinline__ V sroot3(V x) { return vcopysign(hw_exp2(hw_log2(vabs(x)) * (1.0f / 3.0f)), x); }
+template <class V>
+__device__ __forceinline__ V sroot4(V x) { return vcopysign(hw_sqrt(hw_sqrt(vabs(x))), x); }
 
-// sRGB inverse EOTF (colour.cctf_encoding): linear -> encoded
-__device__ __forceinline__ float srgb_encode(float L) {
-  const float hi = fmaf(1.055f, pow_pos(L, 1.0f / 2.4f), -0.055f);
-  const float lo = L * 12.92f;
-  return L <= 0.0031308f ? lo : hi;
+// sRGB inverse EOTF (colour.cctf_encoding): linear -> encoded.  x ** p = exp2(p * log2 x) on the power
+// segment only (x > 0 there); everything else, negatives included, takes the linear segment.
+template <class V>
+__device__ __forceinline__ V srgb_encode(V L) {
+  const V hi = mad<V>(hw_exp2(hw_log2(L) * (1.0f / 2.4f)), 1.055f, -0.055f);
+  const V lo = L * 12.92f;
+  return L <= (V)(0.0031308f) ? lo : hi;
 }
 
 // sRGB EOTF (colour.cctf_decoding): encoded -> linear
-__device__ __forceinline__ float srgb_decode(float V) {
-  const float t = fmaf(V, 1.0f / 1.055f, 0.055f / 1.055f);
-  const float hi = pow_pos(t, 2.4f);
-  const float lo = V * (1.0f / 12.92f);
-  return V <= 0.040449936f ? lo : hi;
+template <class V>
+__device__ __forceinline__ V srgb_decode(V v) {
+  const V t = mad<V>(v, 1.0f / 1.055f, 0.055f / 1.055f);
+  const V hi = hw_exp2(hw_log2(t) * 2.4f);
+  const V lo = v * (1.0f / 12.92f);
+  return v <= (V)(0.040449936f) ? lo : hi;
 }
 
 // CIE 1976 intermediate lightness function and its inverse
-__device__ __forceinline__ float lab_f(float t) {
-  const float hi = hw_exp2(hw_log2(t) * (1.0f / 3.0f));
-  const float lo = fmaf(t, 841.0f / 108.0f, 16.0f / 116.0f);
-  return t > 0.008856451679035631f ? hi : lo;
+template <class V>
+__device__ __forceinline__ V lab_f(V t) {
+  const V hi = hw_exp2(hw_log2(t) * (1.0f / 3.0f));
+  const V lo = mad<V>(t, 841.0f / 108.0f, 16.0f / 116.0f);
+  return t > (V)(0.008856451679035631f) ? hi : lo;
 }
-__device__ __forceinline__ float lab_finv(float f) {
-  const float hi = f * f * f;
-  const float lo = (f - 16.0f / 116.0f) * (108.0f / 841.0f);
-  return f > 24.0f / 116.0f ? hi : lo;
+template <class V>
+__device__ __forceinline__ V lab_finv(V f) {
+  const V hi = f * f * f;
+  const V lo = (f - 16.0f / 116.0f) * (108.0f / 841.0f);
+  return f > (V)(24.0f / 116.0f) ? hi : lo;
 }
 
 // ---- colour space conversions (the reference treats its data as sRGB-ENCODED here) ----------
 
-__device__ __forceinline__ float rgb_to_fy(const Px p, const ChainParams& P) {
-  const float r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
-  return lab_f(fmaf(P.m_fwd[3], r, fmaf(P.m_fwd[4], g, P.m_fwd[5] * b)));
-}
-
-__device__ __forceinline__ Lab rgb_to_lab(const Px p, const ChainParams& P) {
-  const float r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
-  const float fx = lab_f(fmaf(P.m_fwd[0], r, fmaf(P.m_fwd[1], g, P.m_fwd[2] * b)));
-  const float fy = lab_f(fmaf(P.m_fwd[3], r, fmaf(P.m_fwd[4], g, P.m_fwd[5] * b)));
-  const float fz = lab_f(fmaf(P.m_fwd[6], r, fmaf(P.m_fwd[7], g, P.m_fwd[8] * b)));
-  Lab o;
-  o.L = fmaf(116.0f, fy, -16.0f);
-  o.a = 500.0f * (fx - fy);
-  o.b = 200.0f * (fy - fz);
+template <class V>
+__device__ __forceinline__ LabT<V> rgb_to_lab(const PxT<V> p, const ChainParams& P) {
+  const V r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
+  const V fx = lab_f(mad<V>(P.m_fwd[0], r, mad<V>(P.m_fwd[1], g, b * P.m_fwd[2])));
+  const V fy = lab_f(mad<V>(P.m_fwd[3], r, mad<V>(P.m_fwd[4], g, b * P.m_fwd[5])));
+  const V fz = lab_f(mad<V>(P.m_fwd[6], r, mad<V>(P.m_fwd[7], g, b * P.m_fwd[8])));
+  LabT<V> o;
+  o.L = mad<V>(fy, 116.0f, -16.0f);
+  o.a = (fx - fy) * 500.0f;
+  o.b = (fy - fz) * 200.0f;
   return o;
 }
 
 // _lab_to_rgb: Lab -> XYZ -> sRGB (encoded) -> clip
-__device__ __forceinline__ Px lab_to_rgb(const Lab q, const ChainParams& P) {
-  const float fy = fmaf(q.L, 1.0f / 116.0f, 16.0f / 116.0f);
-  const float fx = fmaf(q.a, 1.0f / 500.0f, fy);
-  const float fz = fmaf(q.b, -1.0f / 200.0f, fy);
-  const float x = lab_finv(fx), y = lab_finv(fy), z = lab_finv(fz);
-  Px o;
-  o.r = clamp01(srgb_encode(fmaf(P.m_inv[0], x, fmaf(P.m_inv[1], y, P.m_inv[2] * z))));
-  o.g = clamp01(srgb_encode(fmaf(P.m_inv[3], x, fmaf(P.m_inv[4], y, P.m_inv[5] * z))));
-  o.b = clamp01(srgb_encode(fmaf(P.m_inv[6], x, fmaf(P.m_inv[7], y, P.m_inv[8] * z))));
+template <class V>
+__device__ __forceinline__ PxT<V> lab_to_rgb(const LabT<V> q, const ChainParams& P) {
+  const V fy = mad<V>(q.L, 1.0f / 116.0f, 16.0f / 116.0f);
+  const V fx = mad<V>(q.a, 1.0f / 500.0f, fy);
+  const V fz = mad<V>(q.b, -1.0f / 200.0f, fy);
+  const V x = lab_finv(fx), y = lab_finv(fy), z = lab_finv(fz);
+  PxT<V> o;
+  o.r = clamp01(srgb_encode(mad<V>(P.m_inv[0], x, mad<V>(P.m_inv[1], y, z * P.m_inv[2]))));
+  o.g = clamp01(srgb_encode(mad<V>(P.m_inv[3], x, mad<V>(P.m_inv[4], y, z * P.m_inv[5]))));
+  o.b = clamp01(srgb_encode(mad<V>(P.m_inv[6], x, mad<V>(P.m_inv[7], y, z * P.m_inv[8]))));
   return o;
 }
 
 // ---- colour correction ---------------------------------------------------------------------
 
 // dot product of T expansion terms with the staged table M[t] = {cR, cG, cB, 0} (LDS, broadcast reads)
-template <int T>
-__device__ __forceinline__ Px ccm_dot(const float (&e)[T], const float4* __restrict__ M) {
+template <int T, class V>
+__device__ __forceinline__ PxT<V> ccm_dot(const V (&e)[T], const float4* __restrict__ M) {
   float4 c = M[0];
-  Px o;
+  PxT<V> o;
   o.r = e[0] * c.x;
   o.g = e[0] * c.y;
   o.b = e[0] * c.z;
 #pragma unroll
   for (int t = 1; t < T; ++t) {
     c = M[t];
-    o.r = fmaf(e[t], c.x, o.r);
-    o.g = fmaf(e[t], c.y, o.g);
-    o.b = fmaf(e[t], c.z, o.b);
+    o.r = mad<V>(e[t], c.x, o.r);
+    o.g = mad<V>(e[t], c.y, o.g);
+    o.b = mad<V>(e[t], c.z, o.b);
   }
   return o;
 }
 
-__device__ __forceinline__ Px ccm_linear3(const Px p, const ChainParams& P) {
-  Px o;
-  o.r = fmaf(P.ccm3[2], p.b, fmaf(P.ccm3[1], p.g, P.ccm3[0] * p.r));
-  o.g = fmaf(P.ccm3[5], p.b, fmaf(P.ccm3[4], p.g, P.ccm3[3] * p.r));
-  o.b = fmaf(P.ccm3[8], p.b, fmaf(P.ccm3[7], p.g, P.ccm3[6] * p.r));
+template <class V>
+__device__ __forceinline__ PxT<V> ccm_linear3(const PxT<V> p, const ChainParams& P) {
+  PxT<V> o;
+  o.r = mad<V>(P.ccm3[2], p.b, mad<V>(P.ccm3[1], p.g, p.r * P.ccm3[0]));
+  o.g = mad<V>(P.ccm3[5], p.b, mad<V>(P.ccm3[4], p.g, p.r * P.ccm3[3]));
+  o.b = mad<V>(P.ccm3[8], p.b, mad<V>(P.ccm3[7], p.g, p.r * P.ccm3[6]));
   return o;
 }
 
 // dot product with a small table held in scalar registers (row-major 3 x T, compile-time indices)
-template <int T>
-__device__ __forceinline__ Px ccm_dot_small(const float (&e)[T], const ChainParams& P) {
-  Px o;
+template <int T, class V>
+__device__ __forceinline__ PxT<V> ccm_dot_small(const V (&e)[T], const ChainParams& P) {
+  PxT<V> o;
   o.r = e[0] * P.ccm_small[0];
   o.g = e[0] * P.ccm_small[T];
   o.b = e[0] * P.ccm_small[2 * T];
 #pragma unroll
   for (int t = 1; t < T; ++t) {
-    o.r = fmaf(e[t], P.ccm_small[t], o.r);
-    o.g = fmaf(e[t], P.ccm_small[T + t], o.g);
-    o.b = fmaf(e[t], P.ccm_small[2 * T + t], o.b);
+    o.r = mad<V>(e[t], P.ccm_small[t], o.r);
+    o.g = mad<V>(e[t], P.ccm_small[T + t], o.g);
+    o.b = mad<V>(e[t], P.ccm_small[2 * T + t], o.b);
   }
   return o;
 }
 
 // 3 < T <= 8: Cheung 2004 with 5, 7 or 8 terms, Finlayson 2015 root-polynomial of degree 2 (6 terms)
-__device__ __forceinline__ Px ccm_small_terms(const Px p, const ChainParams& P) {
-  const float R = p.r, G = p.g, B = p.b;
+template <class V>
+__device__ __forceinline__ PxT<V> ccm_small_terms(const PxT<V> p, const ChainParams& P) {
+  const V R = p.r, G = p.g, B = p.b;
+  const V one = (V)(1.0f);
   switch (P.ccm_terms) {
     case 5: {
-      const float e[5] = {R, G, B, R * G * B, 1.0f};
-      return ccm_dot_small<5>(e, P);
+      const V e[5] = {R, G, B, R * G * B, one};
+      return ccm_dot_small<5, V>(e, P);
     }
     case 6: {
-      const float e[6] = {R, G, B, sroot2(R * G), sroot2(G * B), sroot2(R * B)};
-      return ccm_dot_small<6>(e, P);
+      const V e[6] = {R, G, B, sroot2(R * G), sroot2(G * B), sroot2(R * B)};
+      return ccm_dot_small<6, V>(e, P);
     }
     case 7: {
-      const float e[7] = {R, G, B, R * G, R * B, G * B, 1.0f};
-      return ccm_dot_small<7>(e, P);
+      const V e[7] = {R, G, B, R * G, R * B, G * B, one};
+      return ccm_dot_small<7, V>(e, P);
     }
     default: {  // 8
-      const float e[8] = {R, G, B, R * G, R * B, G * B, R * G * B, 1.0f};
-      return ccm_dot_small<8>(e, P);
+      const V e[8] = {R, G, B, R * G, R * B, G * B, R * G * B, one};
+      return ccm_dot_small<8, V>(e, P);
     }
   }
 }
@@ -217,104 +257,107 @@ __device__ __forceinline__ void stage_ccm(const ChainParams& P, float4* __restri
 }
 
 // colour.characterisation.matrix_augmented_Cheung2004 term lists
-__device__ __forceinline__ Px ccm_cheung(const Px p, const int terms, const float4* __restrict__ M) {
-  const float R = p.r, G = p.g, B = p.b;
+template <class V>
+__device__ __forceinline__ PxT<V> ccm_cheung(const PxT<V> p, const int terms, const float4* __restrict__ M) {
+  const V R = p.r, G = p.g, B = p.b;
+  const V one = (V)(1.0f);
   switch (terms) {
     case 3: {
-      const float e[3] = {R, G, B};
-      return ccm_dot<3>(e, M);
+      const V e[3] = {R, G, B};
+      return ccm_dot<3, V>(e, M);
     }
     case 5: {
-      const float e[5] = {R, G, B, R * G * B, 1.0f};
-      return ccm_dot<5>(e, M);
+      const V e[5] = {R, G, B, R * G * B, one};
+      return ccm_dot<5, V>(e, M);
     }
     case 7: {
-      const float e[7] = {R, G, B, R * G, R * B, G * B, 1.0f};
-      return ccm_dot<7>(e, M);
+      const V e[7] = {R, G, B, R * G, R * B, G * B, one};
+      return ccm_dot<7, V>(e, M);
     }
     case 8: {
-      const float e[8] = {R, G, B, R * G, R * B, G * B, R * G * B, 1.0f};
-      return ccm_dot<8>(e, M);
+      const V e[8] = {R, G, B, R * G, R * B, G * B, R * G * B, one};
+      return ccm_dot<8, V>(e, M);
     }
     case 10: {
-      const float e[10] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, 1.0f};
-      return ccm_dot<10>(e, M);
+      const V e[10] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, one};
+      return ccm_dot<10, V>(e, M);
     }
     case 11: {
-      const float e[11] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B, 1.0f};
-      return ccm_dot<11>(e, M);
+      const V e[11] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B, one};
+      return ccm_dot<11, V>(e, M);
     }
     case 14: {
-      const float e[14] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
-                           R * R * R, G * G * G, B * B * B, 1.0f};
-      return ccm_dot<14>(e, M);
+      const V e[14] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                       R * R * R, G * G * G, B * B * B, one};
+      return ccm_dot<14, V>(e, M);
     }
     case 16: {
-      const float e[16] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
-                           R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B};
-      return ccm_dot<16>(e, M);
+      const V e[16] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                       R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B};
+      return ccm_dot<16, V>(e, M);
     }
     case 17: {
-      const float e[17] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
-                           R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B, 1.0f};
-      return ccm_dot<17>(e, M);
+      const V e[17] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                       R * R * G, G * G * B, B * B * R, R * R * R, G * G * G, B * B * B, one};
+      return ccm_dot<17, V>(e, M);
     }
     case 19: {
-      const float e[19] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
-                           R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
-                           R * R * R, G * G * G, B * B * B};
-      return ccm_dot<19>(e, M);
+      const V e[19] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                       R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
+                       R * R * R, G * G * G, B * B * B};
+      return ccm_dot<19, V>(e, M);
     }
     case 20: {
-      const float e[20] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
-                           R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
-                           R * R * R, G * G * G, B * B * B, 1.0f};
-      return ccm_dot<20>(e, M);
+      const V e[20] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                       R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
+                       R * R * R, G * G * G, B * B * B, one};
+      return ccm_dot<20, V>(e, M);
     }
     default: {  // 22
-      const float e[22] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
-                           R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
-                           R * R * R, G * G * G, B * B * B, R * R * G * B, R * G * G * B, R * G * B * B};
-      return ccm_dot<22>(e, M);
+      const V e[22] = {R, G, B, R * G, R * B, G * B, R * R, G * G, B * B, R * G * B,
+                       R * R * G, G * G * B, B * B * R, R * R * B, G * G * R, B * B * G,
+                       R * R * R, G * G * G, B * B * B, R * R * G * B, R * G * G * B, R * G * B * B};
+      return ccm_dot<22, V>(e, M);
     }
   }
 }
 
 // colour.characterisation.polynomial_expansion_Finlayson2015(root_polynomial_expansion=True)
-__device__ __forceinline__ Px ccm_rootpoly(const Px p, const int terms, const float4* __restrict__ M) {
-  const float R = p.r, G = p.g, B = p.b;
-  const float rg = R * G, gb = G * B, rb = R * B;
+template <class V>
+__device__ __forceinline__ PxT<V> ccm_rootpoly(const PxT<V> p, const int terms, const float4* __restrict__ M) {
+  const V R = p.r, G = p.g, B = p.b;
+  const V rg = R * G, gb = G * B, rb = R * B;
   switch (terms) {
     case 3: {
-      const float e[3] = {R, G, B};
-      return ccm_dot<3>(e, M);
+      const V e[3] = {R, G, B};
+      return ccm_dot<3, V>(e, M);
     }
     case 6: {
-      const float e[6] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb)};
-      return ccm_dot<6>(e, M);
+      const V e[6] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb)};
+      return ccm_dot<6, V>(e, M);
     }
     case 13: {
-      const float e[13] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
-                           sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
-                           sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B)};
-      return ccm_dot<13>(e, M);
+      const V e[13] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
+                       sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
+                       sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B)};
+      return ccm_dot<13, V>(e, M);
     }
     default: {  // 22
-      const float e[22] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
-                           sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
-                           sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B),
-                           sroot4(R * R * rg), sroot4(R * R * rb), sroot4(G * G * rg),
-                           sroot4(G * G * gb), sroot4(B * B * rb), sroot4(B * B * gb),
-                           sroot4(R * rg * B), sroot4(G * rg * B), sroot4(B * rb * G)};
-      return ccm_dot<22>(e, M);
+      const V e[22] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
+                       sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
+                       sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B),
+                       sroot4(R * R * rg), sroot4(R * R * rb), sroot4(G * G * rg),
+                       sroot4(G * G * gb), sroot4(B * B * rb), sroot4(B * B * gb),
+                       sroot4(R * rg * B), sroot4(G * rg * B), sroot4(B * rb * G)};
+      return ccm_dot<22, V>(e, M);
     }
   }
 }
 
 enum CcmClass { CCM_NONE = 0, CCM_LIN3 = 1, CCM_CHEUNG = 2, CCM_ROOT = 3, CCM_RUNTIME = 4, CCM_SMALL = 5 };
 
-template <int CCMC>
-__device__ __forceinline__ Px apply_ccm(const Px p, const ChainParams& P, const float4* __restrict__ M) {
+template <int CCMC, class V>
+__device__ __forceinline__ PxT<V> apply_ccm(const PxT<V> p, const ChainParams& P, const float4* __restrict__ M) {
   if constexpr (CCMC == CCM_NONE) {
     return p;
   } else if constexpr (CCMC == CCM_LIN3) {
@@ -356,26 +399,29 @@ __device__ __forceinline__ ImgParams load_img_params(const ChainParams& P, int i
 
 // ---- stage 4: shadows / highlights on Lab (editingTools.py:508-536) --------------------------
 
-__device__ __forceinline__ Lab sh_on_lab(Lab q, const ChainParams& P) {
-  const float Ln = q.L * 0.01f;
-  const float hadj = P.sh_hs != 0.0f ? P.sh_hs * (hw_exp2(Ln * P.sh_log2f) - 1.0f) : 0.0f;
-  const float sadj = P.sh_ss != 0.0f ? P.sh_ss * (hw_exp2((1.0f - Ln) * P.sh_log2f) - 1.0f) : 0.0f;
-  const float total = (hadj + sadj) * 100.0f;
+template <class V>
+__device__ __forceinline__ LabT<V> sh_on_lab(LabT<V> q, const ChainParams& P) {
+  const V Ln = q.L * 0.01f;
+  V total = (V)(0.0f);
+  if (P.sh_hs != 0.0f) total = (hw_exp2(Ln * P.sh_log2f) - 1.0f) * P.sh_hs;
+  if (P.sh_ss != 0.0f) total = mad<V>(hw_exp2((1.0f - Ln) * P.sh_log2f) - 1.0f, P.sh_ss, total);
+  total = total * 100.0f;
   q.L = clampf(q.L + total, 0.0f, 100.0f);
   if (P.sh_chroma) {
-    const float cs = 1.0f - clampf(fabsf(total) * (0.05f / 20.0f), 0.0f, 0.2f);
-    q.a *= cs;
-    q.b *= cs;
+    const V cs = 1.0f - clampf(vabs(total) * (0.05f / 20.0f), 0.0f, 0.2f);
+    q.a = q.a * cs;
+    q.b = q.b * cs;
   }
   return q;
 }
 
-// ---- stages 1-4 on one pixel -----------------------------------------------------------------
+// ---- stages 1-4 --------------------------------------------------------------------------------
 
 // PLAIN = the caller guarantees: no negative inversion, exactly one gain stage, no shadows/highlights,
 // RGB data.  Everything else about a chain is then dead code and its parameters never reach registers.
-template <int CCMC, bool SH, bool PLAIN = false>
-__device__ __forceinline__ Px front(Px p, const ChainParams& P, const ImgParams& ip, const float4* __restrict__ M) {
+template <int CCMC, bool SH, bool PLAIN = false, class V = float>
+__device__ __forceinline__ PxT<V> front(PxT<V> p, const ChainParams& P, const ImgParams& ip,
+                                        const float4* __restrict__ M) {
   if constexpr (PLAIN) {
     p = apply_ccm<CCMC>(p, P, M);
     p.r = clamp01(p.r * ip.gain0[0]);
@@ -407,8 +453,8 @@ __device__ __forceinline__ Px front(Px p, const ChainParams& P, const ImgParams&
   if constexpr (SH) {
     if (P.sh) {
       if (P.lab_io) {
-        const Lab q = sh_on_lab(Lab{p.r, p.g, p.b}, P);
-        p = Px{q.L, q.a, q.b};
+        const LabT<V> q = sh_on_lab(LabT<V>{p.r, p.g, p.b}, P);
+        p = PxT<V>{q.L, q.a, q.b};
       } else {
         p = lab_to_rgb(sh_on_lab(rgb_to_lab(p, P), P), P);
       }
@@ -419,21 +465,20 @@ __device__ __forceinline__ Px front(Px p, const ChainParams& P, const ImgParams&
 
 // ---- stage 5 pointwise part: unsharp mask on (Ln, blurred Ln) (editingTools.py:767-809) -------
 
-template <bool PLAIN = false>
-__device__ __forceinline__ Lab usm_on_lab(const float Ln, const float a, const float b, const float Lb,
-                                          const ChainParams& P) {
-  float um = Ln - Lb;
+template <bool PLAIN = false, class V = float>
+__device__ __forceinline__ LabT<V> usm_on_lab(const V Ln, const V a, const V b, const V Lb, const ChainParams& P) {
+  V um = Ln - Lb;
   if (!PLAIN && P.usm_thr > 0.0f) {
-    const float es = fabsf(um);
-    um *= es > P.usm_thr ? 1.0f : es * P.usm_inv_thr;
+    const V es = vabs(um);
+    um = um * (es > (V)(P.usm_thr) ? (V)(1.0f) : es * P.usm_inv_thr);
   }
-  const float hm = Ln > 0.9f ? 1.0f - (Ln - 0.9f) * 10.0f : 1.0f;
-  const float sm = Ln < 0.1f ? Ln * 10.0f : 1.0f;
-  const float ad = clampf(hm * sm, 0.1f, 1.0f);
-  Lab o;
-  o.L = clamp01(fmaf(um * P.usm_amount_scaled, ad, Ln)) * 100.0f;
+  const V hm = Ln > (V)(0.9f) ? mad<V>(Ln - 0.9f, -10.0f, 1.0f) : (V)(1.0f);
+  const V sm = Ln < (V)(0.1f) ? Ln * 10.0f : (V)(1.0f);
+  const V ad = clampf(hm * sm, 0.1f, 1.0f);
+  LabT<V> o;
+  o.L = clamp01(mad<V>(um * P.usm_amount_scaled, ad, Ln)) * 100.0f;
   if (P.usm_chroma) {
-    const float boost = fmaf(fabsf(um), P.usm_chroma_k, 1.0f);
+    const V boost = mad<V>(vabs(um), P.usm_chroma_k, 1.0f);
     o.a = clampf(a * boost, -127.0f, 127.0f);
     o.b = clampf(b * boost, -127.0f, 127.0f);
   } else {
@@ -445,8 +490,8 @@ __device__ __forceinline__ Lab usm_on_lab(const float Ln, const float a, const f
 
 // ---- stages 6-7: final clip, encoding, quantisation -------------------------------------------
 
-template <int OUT, bool IN_RANGE = false>
-__device__ __forceinline__ Px finish(Px p, const ChainParams& P) {
+template <int OUT, bool IN_RANGE = false, class V = float>
+__device__ __forceinline__ PxT<V> finish(PxT<V> p, const ChainParams& P) {
   if (!IN_RANGE && P.final_clip) {
     p.r = clamp01(p.r);
     p.g = clamp01(p.g);

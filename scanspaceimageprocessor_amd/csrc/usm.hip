@@ -26,6 +26,12 @@ constexpr int USM_TH = 32;   // tile height
 constexpr int USM_NT = SS_USM_NT;  // threads per workgroup
 constexpr int USM_WAVES_PER_SIMD = 2 * USM_NT / 256;  // two workgroups per CU
 
+#ifdef SS_ABL_NO_BARRIER  // timing experiment only (results are wrong without the barriers)
+#define USM_SYNC() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define USM_SYNC() __syncthreads()
+#endif
+
 #ifndef SS_USM_PREFETCH
 #define SS_USM_PREFETCH 13  // phase-1 pixels in flight per thread (13 = the whole tile at r = 6)
 #endif
@@ -73,17 +79,19 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
 
 // R_T : compile-time blur radius (3 <-> sigma 1, 6 <-> sigma 2), 0 = runtime radius P.usm_r.
 // CCMC: CCM_LIN3 for the reference's 3-term correction, CCM_RUNTIME for everything else.
-// Tile walk: workgroup b serves "XCD" b % 8 (workgroups are dealt round-robin over the 8 XCDs, so
-// b and b + 8 share an L2); every XCD gets one contiguous band of the tile sequence and its workgroups
-// walk that band side by side, so that tiles sharing halo pixels meet in the same L2 close in time.
-// Placement only affects speed: any assignment of tiles to workgroups is correct.
-struct TileWalk {
-  int tiles_x, tiles_y, tiles_per_img;
-  int64_t n_tiles;  // whole batch
+//
+// Strip walk: the tile grid of every image is cut into vertical segments of `seg_tiles` tiles, one tile
+// wide.  A workgroup takes whole segments and walks each top to bottom.  Consecutive tiles of a segment
+// share 2r rows of halo: after a tile's phase 3 the bottom 2r rows of both LDS planes are moved to the top
+// (through registers, across the tile's closing barrier), so only the first tile of a segment computes
+// its upper halo.  Any assignment of segments to workgroups is correct; the order only affects speed.
+struct StripWalk {
+  int tiles_x, tiles_y, seg_tiles, segs_y;
+  int64_t n_segments;  // whole batch
 };
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>
-__global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const TileWalk T,
+__global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const StripWalk T,
                                                      const float* __restrict__ src, void* __restrict__ dst) {
   constexpr int TW = USM_TW, TH = USM_TH, NT = USM_NT;
   extern __shared__ __attribute__((aligned(16))) float S[];
@@ -102,171 +110,286 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   float* __restrict__ AB = Ht + PH * TW;  // [TH][TW][2] a, b of the tile's pixels
   const int W = P.width, H = P.height;
   const int tid = threadIdx.x;
-  const int n_slots = PH * PWv;
-  // phase-1 slots per thread; known at compile time for the common radii so that every pixel load
-  // of a tile can be issued before the first one is consumed
-  constexpr int ITERS = R_T ? ((TH + 2 * R_T) * (TW + 2 * R_T) + NT - 1) / NT : 1;
+  // Rows every tile computes itself: LDS rows [2r, PH) ("new rows", TH of them: image rows y0+r ... y0+TH+r-1).
+  // Thread -> slot map of the new rows, affine in the slot number k so that no per-slot index lives in a
+  // register: MAIN slots cover the TW tile columns (row 4k + tid/128, column tid%128 at NT = 512), one SIDE
+  // slot per thread covers the 2r halo columns.
+  const int n_new = TH * PWv;
+  constexpr int ROWS_PER_PASS = NT / TW;        // 4
+  constexpr int MAIN = TH / ROWS_PER_PASS;      // 8 main slots per thread
+  static_assert(NT % TW == 0 && TH % (NT / TW) == 0, "tile shape must divide the workgroup");
+  static_assert(2 * (R_T ? R_T : 1) * TH <= NT, "one side slot per thread at most");
+  const int m_row = tid / TW, m_col = tid - m_row * TW;  // main slots: new row 4k + m_row, tile column m_col
+  const int s_row = tid / (2 * r), s_j = tid - s_row * (2 * r);
+  const int s_lx = s_j < r ? s_j : s_j + TW;             // side slot: new row s_row, LDS column s_lx
+  const bool s_on = tid < 2 * r * TH;
+  // float4 moves per thread for the carried rows: 2r rows of Lt (PW floats) and of Ht (TW floats)
+  constexpr int CARRY_MAX = (2 * SS_MAX_USM_RADIUS * ((USM_TW + 2 * SS_MAX_USM_RADIUS + 3) / 4 + USM_TW / 4) + NT - 1) / NT;
+  constexpr int CARRY = R_T ? (2 * R_T * ((TW + 2 * R_T + 3) / 4 + TW / 4) + NT - 1) / NT : CARRY_MAX;
+  const int carry_lt = 2 * r * (PW / 4), carry_n = carry_lt + 2 * r * (TW / 4);
 
-  // this workgroup's share of the tile sequence
-  const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-  const int64_t band = (T.n_tiles + 7) >> 3;
-  const int64_t band_begin = xcd * band;
-  const int64_t band_end = band_begin + band < T.n_tiles ? band_begin + band : T.n_tiles;
+  // ---- the walk: (segment, tile) positions of this workgroup, flattened so that the pixel loads of the
+  // NEXT tile can be issued while the current tile is still in its phases 2 and 3 ----
+  struct TilePos {
+    int64_t seg;
+    int img, x0, ty, ty_begin, ty_end;
+    bool valid;
+  };
+  auto seg_pos = [&](int64_t seg) -> TilePos {
+    TilePos t;
+    t.seg = seg;
+    t.valid = seg < T.n_segments;
+    const int per_img = T.tiles_x * T.segs_y;
+    t.img = (int)(seg / per_img);
+    const int s_in = (int)(seg - (int64_t)t.img * per_img);
+    const int sy = s_in / T.tiles_x;
+    t.x0 = (s_in - sy * T.tiles_x) * TW;
+    t.ty_begin = sy * T.seg_tiles;
+    t.ty_end = t.ty_begin + T.seg_tiles < T.tiles_y ? t.ty_begin + T.seg_tiles : T.tiles_y;
+    t.ty = t.ty_begin;
+    return t;
+  };
+  auto next_pos = [&](TilePos t) -> TilePos {
+    if (t.ty + 1 < t.ty_end) {
+      t.ty += 1;
+      return t;
+    }
+    return seg_pos(t.seg + gridDim.x);
+  };
+  // source pixel index of LDS slot (ly, lx) of the tile at (x0, y0)
+  auto slot_src = [&](int x0, int y0, bool interior, int ly, int lx) -> uint32_t {
+    int py = y0 - r + ly, px = x0 - r + lx;
+    if (!interior) {
+      py = reflect_coord(py, H);
+      px = reflect_coord(px, W);
+    }
+    return (uint32_t)py * W + px;
+  };
+  auto is_interior = [&](int x0, int y0) -> bool {
+    // tiles whose halo stays inside the image skip the border arithmetic
+    return x0 >= r && y0 >= r && x0 + TW + r <= W && y0 + TH + r <= H;
+  };
+  // Fast path: compile-time radius and a colour correction small enough to unroll.  The other kernels walk
+  // their slots with plain loops and never carry rows between tiles (the launcher gives them 1-tile segments).
+  constexpr bool PREFETCH = R_T != 0 && !ccm_needs_table<CCMC>;
+  F3 v[MAIN + 1];
+  // issue every pixel load of a tile's new rows
+  auto issue_loads = [&](const TilePos& t) {
+    if constexpr (PREFETCH) {
+      const int y0 = t.ty * TH;
+      const bool interior = is_interior(t.x0, y0);
+      const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)t.img * P.n_px * 3);
+#ifdef SS_ABL_NO_LOAD
+#pragma unroll
+      for (int k = 0; k <= MAIN; ++k) v[k] = F3{(float)(tid + k) * 1e-4f, (float)k * 1e-2f, 0.5f};
+#else
+#pragma unroll
+      for (int k = 0; k < MAIN; ++k)
+        v[k] = s[slot_src(t.x0, y0, interior, 2 * r + ROWS_PER_PASS * k + m_row, r + m_col)];
+      if (s_on) v[MAIN] = s[slot_src(t.x0, y0, interior, 2 * r + s_row, s_lx)];
+#endif
+    }
+  };
 
   int cur_img = -1;
   ImgParams ip;
-  for (int64_t tile = band_begin + lane_in_xcd; tile < band_end; tile += wg_per_xcd) {
-    const int img = (int)(tile / T.tiles_per_img);
-    const int t_in = (int)(tile - (int64_t)img * T.tiles_per_img);
-    const int ty = t_in / T.tiles_x, tx = t_in - ty * T.tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-    if (img != cur_img) {
-      ip = load_img_params(P, img);
-      cur_img = img;
-    }
-    const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * P.n_px * 3);
-    // tiles whose halo stays inside the image skip the border arithmetic
-    const bool interior = x0 >= r && y0 >= r && x0 + TW + r <= W && y0 + TH + r <= H;
+  TilePos cur = seg_pos(blockIdx.x);
+  if (cur.valid) issue_loads(cur);
+  while (cur.valid) {
+    const TilePos nxt = next_pos(cur);
+    {
+      const int img = cur.img, x0 = cur.x0, ty = cur.ty;
+      if (img != cur_img) {
+        ip = load_img_params(P, img);
+        cur_img = img;
+      }
+      const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * P.n_px * 3);
+      char* d = reinterpret_cast<char*>(dst) + (size_t)img * P.n_px * 3 * OutTraits<OUT>::BYTES;
+      const int y0 = ty * TH;
+      const bool first = ty == cur.ty_begin;
+      const bool interior = is_interior(x0, y0);
 
-    // ---- phase 1: stages 1-4 + RGB -> Lab for the tile and its halo ----
-    auto slot_src = [&](int idx, int& ly, int& lx) -> uint32_t {
-      ly = idx / PWv;
-      lx = idx - ly * PWv;
-      int sy = y0 - r + ly, sx = x0 - r + lx;
-      if (!interior) {
-        sy = reflect_coord(sy, H);
-        sx = reflect_coord(sx, W);
-      }
-      return (uint32_t)sy * W + sx;
-    };
-    auto slot_compute = [&](const F3 v, int ly, int lx) {
-      const Px p = front<CCMC, true, PLAIN>(Px{v.x, v.y, v.z}, P, ip, M);
-      Lab q;
-      if (!PLAIN && P.lab_io) {
-        q = Lab{p.r, p.g, p.b};
-      } else {
-        q = rgb_to_lab(p, P);
-      }
-      Lt[ly * PW + lx] = q.L * 0.01f;
-      const int cy = ly - r, cx = lx - r;
-      if ((unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW) {
-        *reinterpret_cast<float2*>(AB + (cy * TW + cx) * 2) = make_float2(q.a, q.b);
-      }
-    };
-    if constexpr (R_T != 0 && !ccm_needs_table<CCMC>) {
-      // pixels are fetched in groups of PF: every load of a group is issued before its first use
-      // (not for the generic colour-correction code, which is too large to unroll)
-      constexpr int PF = SS_USM_PREFETCH < ITERS ? SS_USM_PREFETCH : ITERS;
-#pragma unroll
-      for (int k0 = 0; k0 < ITERS; k0 += PF) {
-        F3 v[PF];
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-          const int idx = tid + (k0 + k) * NT;
-          int ly, lx;
-          if (k0 + k < ITERS && idx < n_slots) v[k] = s[slot_src(idx, ly, lx)];
+      // ---- phase 1: stages 1-4 + RGB -> Lab, Ln to LDS for every slot, (a, b) for the tile's own pixels ----
+      auto slot_lab = [&](const F3 px) -> Lab {
+#ifdef SS_ABL_NO_P1  // timing experiment: phase 1 without its arithmetic
+        return Lab{px.x * 100.0f, px.y, px.z};
+#else
+        const Px p = front<CCMC, true, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M);
+        if (!PLAIN && P.lab_io) return Lab{p.r, p.g, p.b};
+        return rgb_to_lab(p, P);
+#endif
+      };
+      auto slot_compute = [&](const F3 px, int ly, int lx) {
+        const Lab q = slot_lab(px);
+        Lt[ly * PW + lx] = q.L * 0.01f;
+        const int cy = ly - r, cx = lx - r;
+        if ((unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW) {
+          *reinterpret_cast<float2*>(AB + (cy * TW + cx) * 2) = make_float2(q.a, q.b);
         }
+      };
+      if (first) {  // upper halo rows [0, 2r): only the first tile of a segment has to compute them
+        for (int idx = tid; idx < 2 * r * PWv; idx += NT) {
+          const int ly = idx / PWv, lx = idx - ly * PWv;
+          slot_compute(s[slot_src(x0, y0, interior, ly, lx)], ly, lx);
+        }
+      }
+      // (a, b) of the last r new rows belong to the NEXT tile's first r rows: they wait in registers until
+      // this tile's phase 3 is done with the plane
+      constexpr int DEFER = PREFETCH ? (R_T + ROWS_PER_PASS - 1) / ROWS_PER_PASS + 1 : 1;
+      float2 late_ab[DEFER];
+      if constexpr (PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-          const int idx = tid + (k0 + k) * NT;
-          if (k0 + k < ITERS && idx < n_slots) {
-            const int ly = idx / PWv;
-            slot_compute(v[k], ly, idx - ly * PWv);
+        for (int k = 0; k < MAIN; ++k) {
+          const int ln = ROWS_PER_PASS * k + m_row;  // new-row number, AB row r + ln
+          const Lab q = slot_lab(v[k]);
+          Lt[(2 * r + ln) * PW + r + m_col] = q.L * 0.01f;
+          if (k < MAIN - DEFER) {
+            *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
+          } else {
+            if (r + ln < TH) *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
+            late_ab[k - (MAIN - DEFER)] = make_float2(q.a, q.b);
+          }
+        }
+        if (s_on) Lt[(2 * r + s_row) * PW + s_lx] = slot_lab(v[MAIN]).L * 0.01f;
+      } else {
+        for (int idx = tid; idx < n_new; idx += NT) {
+          const int ly = idx / PWv, lx = idx - ly * PWv;
+          slot_compute(s[slot_src(x0, y0, interior, ly + 2 * r, lx)], ly + 2 * r, lx);
+        }
+      }
+      USM_SYNC();
+      // the registers of this tile's pixels are free again: fetch the next tile's while phases 2 and 3 run
+      if (nxt.valid) issue_loads(nxt);
+
+      // ---- phase 2: row pass over the rows phase 1 has just written ----
+      const int row_begin = first ? 0 : 2 * r;
+      const int n_items = (PH - row_begin) * (TW / 4);
+#ifdef SS_ABL_NO_P2
+      for (int item = tid; item < 0; item += NT) {
+#else
+      for (int item = tid; item < n_items; item += NT) {
+#endif
+        const int row = row_begin + (item >> 5), q = item & 31;
+        const float* base = Lt + row * PW + 4 * q;
+        float4 acc;
+        if constexpr (R_T != 0) {
+          constexpr int NV = (4 + 2 * R_T + 3) / 4;
+          float v[NV * 4];
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(base + 4 * k);
+            v[4 * k + 0] = t.x;
+            v[4 * k + 1] = t.y;
+            v[4 * k + 2] = t.z;
+            v[4 * k + 3] = t.w;
+          }
+          acc = make_float4(v[0] * P.taps[0], v[1] * P.taps[0], v[2] * P.taps[0], v[3] * P.taps[0]);
+#pragma unroll
+          for (int j = 1; j <= 2 * R_T; ++j) {
+            const float t = tap_at<R_T>(P, j);
+            acc.x = fmaf(v[j + 0], t, acc.x);
+            acc.y = fmaf(v[j + 1], t, acc.y);
+            acc.z = fmaf(v[j + 2], t, acc.z);
+            acc.w = fmaf(v[j + 3], t, acc.w);
+          }
+        } else {
+          float w0 = base[0], w1 = base[1], w2 = base[2], w3 = base[3];
+          const float t0 = P.taps[0];
+          acc = make_float4(w0 * t0, w1 * t0, w2 * t0, w3 * t0);
+          for (int j = 1; j <= 2 * r; ++j) {
+            w0 = w1;
+            w1 = w2;
+            w2 = w3;
+            w3 = base[j + 3];
+            const float t = P.taps[j <= r ? j : 2 * r - j];
+            acc.x = fmaf(w0, t, acc.x);
+            acc.y = fmaf(w1, t, acc.y);
+            acc.z = fmaf(w2, t, acc.z);
+            acc.w = fmaf(w3, t, acc.w);
+          }
+        }
+        *reinterpret_cast<float4*>(Ht + row * TW + 4 * q) = acc;
+      }
+      USM_SYNC();
+
+      // ---- phase 3: column pass, mask logic, Lab -> sRGB, encode, store ----
+      for (int pair = tid; pair < TH * TW / 2; pair += NT) {
+        const int ly = pair >> 6, px = (pair & 63) * 2;
+        const float* col = Ht + ly * TW + px;
+        float2 t = *reinterpret_cast<const float2*>(col);
+        v2f blur = v2f{t.x, t.y} * P.taps[0];
+        if constexpr (R_T != 0) {
+#pragma unroll
+          for (int j = 1; j <= 2 * R_T; ++j) {
+            t = *reinterpret_cast<const float2*>(col + j * TW);
+            blur = mad<v2f>(v2f{t.x, t.y}, tap_at<R_T>(P, j), blur);
+          }
+        } else {
+          for (int j = 1; j <= 2 * r; ++j) {
+            t = *reinterpret_cast<const float2*>(col + j * TW);
+            blur = mad<v2f>(v2f{t.x, t.y}, P.taps[j <= r ? j : 2 * r - j], blur);
+          }
+        }
+        const float* lc = Lt + (ly + r) * PW + r + px;
+        const float4 ab = *reinterpret_cast<const float4*>(AB + (ly * TW + px) * 2);
+#ifdef SS_ABL_NO_P3  // timing experiment: phase 3 without its arithmetic
+        Px2 o = Px2{blur, v2f{lc[0], lc[1]} + v2f{ab.x, ab.z}, v2f{ab.y, ab.w}};
+#else
+        const Lab2 q = usm_on_lab<PLAIN, v2f>(v2f{lc[0], lc[1]}, v2f{ab.x, ab.z}, v2f{ab.y, ab.w}, blur, P);
+        Px2 o;
+        if (!PLAIN && P.lab_io) {
+          o = Px2{q.L, q.a, q.b};
+        } else {
+          o = lab_to_rgb(q, P);
+        }
+        // lab_to_rgb leaves [0,1]; the LAB branch has no final clip: either way the clip stage is a no-op here
+        o = finish<OUT, true, v2f>(o, P);
+#endif
+#ifdef SS_ABL_NO_STORE
+        asm volatile("" ::"v"(o.r.x), "v"(o.r.y), "v"(o.g.x), "v"(o.g.y), "v"(o.b.x), "v"(o.b.y));
+#else
+        usm_store_pair<OUT>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
+#endif
+      }
+
+      // ---- carry the bottom 2r rows of both planes to the top for the next tile of the segment ----
+      // read before the barrier (phase 3 only reads the planes), write after it (nobody reads any more)
+      float4 carry[CARRY];
+      const bool more = nxt.valid && nxt.seg == cur.seg;
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < CARRY; ++k) {
+          const int i = tid + k * NT;
+          if (i < carry_lt) {
+            carry[k] = *reinterpret_cast<const float4*>(Lt + TH * PW + 4 * i);
+          } else if (i < carry_n) {
+            carry[k] = *reinterpret_cast<const float4*>(Ht + TH * TW + 4 * (i - carry_lt));
           }
         }
       }
-    } else {
-      for (int idx = tid; idx < n_slots; idx += NT) {
-        int ly, lx;
-        const F3 v = s[slot_src(idx, ly, lx)];
-        slot_compute(v, ly, lx);
+      USM_SYNC();  // phase 3 is done with the planes
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < CARRY; ++k) {
+          const int i = tid + k * NT;
+          if (i < carry_lt) {
+            *reinterpret_cast<float4*>(Lt + 4 * i) = carry[k];
+          } else if (i < carry_n) {
+            *reinterpret_cast<float4*>(Ht + 4 * (i - carry_lt)) = carry[k];
+          }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+          for (int k = MAIN - DEFER; k < MAIN; ++k) {
+            const int ab_row = r + ROWS_PER_PASS * k + m_row - TH;  // row in the next tile's plane
+            if (ab_row >= 0) *reinterpret_cast<float2*>(AB + (ab_row * TW + m_col) * 2) = late_ab[k - (MAIN - DEFER)];
+          }
+        }
+        // the next tile's phase 1 writes Lt rows [2r, PH) and AB rows [r, TH): disjoint from what is written
+        // here, and its own barrier orders these writes before any read
       }
     }
-    __syncthreads();
-
-    // ---- phase 2: row pass ----
-    const int n_items = PH * (TW / 4);
-    for (int item = tid; item < n_items; item += NT) {
-      const int row = item >> 5, q = item & 31;
-      const float* base = Lt + row * PW + 4 * q;
-      float4 acc;
-      if constexpr (R_T != 0) {
-        constexpr int NV = (4 + 2 * R_T + 3) / 4;
-        float v[NV * 4];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          const float4 t = *reinterpret_cast<const float4*>(base + 4 * k);
-          v[4 * k + 0] = t.x;
-          v[4 * k + 1] = t.y;
-          v[4 * k + 2] = t.z;
-          v[4 * k + 3] = t.w;
-        }
-        acc = make_float4(v[0] * P.taps[0], v[1] * P.taps[0], v[2] * P.taps[0], v[3] * P.taps[0]);
-#pragma unroll
-        for (int j = 1; j <= 2 * R_T; ++j) {
-          const float t = tap_at<R_T>(P, j);
-          acc.x = fmaf(v[j + 0], t, acc.x);
-          acc.y = fmaf(v[j + 1], t, acc.y);
-          acc.z = fmaf(v[j + 2], t, acc.z);
-          acc.w = fmaf(v[j + 3], t, acc.w);
-        }
-      } else {
-        float w0 = base[0], w1 = base[1], w2 = base[2], w3 = base[3];
-        const float t0 = P.taps[0];
-        acc = make_float4(w0 * t0, w1 * t0, w2 * t0, w3 * t0);
-        for (int j = 1; j <= 2 * r; ++j) {
-          w0 = w1;
-          w1 = w2;
-          w2 = w3;
-          w3 = base[j + 3];
-          const float t = P.taps[j <= r ? j : 2 * r - j];
-          acc.x = fmaf(w0, t, acc.x);
-          acc.y = fmaf(w1, t, acc.y);
-          acc.z = fmaf(w2, t, acc.z);
-          acc.w = fmaf(w3, t, acc.w);
-        }
-      }
-      *reinterpret_cast<float4*>(Ht + row * TW + 4 * q) = acc;
-    }
-    __syncthreads();
-
-    // ---- phase 3: column pass, mask logic, Lab -> sRGB, encode, store ----
-    char* d = reinterpret_cast<char*>(dst) + (size_t)img * P.n_px * 3 * OutTraits<OUT>::BYTES;
-    for (int pair = tid; pair < TH * TW / 2; pair += NT) {
-      const int ly = pair >> 6, px = (pair & 63) * 2;
-      const float* col = Ht + ly * TW + px;
-      float2 t = *reinterpret_cast<const float2*>(col);
-      float b0 = t.x * P.taps[0], b1 = t.y * P.taps[0];
-      if constexpr (R_T != 0) {
-#pragma unroll
-        for (int j = 1; j <= 2 * R_T; ++j) {
-          t = *reinterpret_cast<const float2*>(col + j * TW);
-          b0 = fmaf(t.x, tap_at<R_T>(P, j), b0);
-          b1 = fmaf(t.y, tap_at<R_T>(P, j), b1);
-        }
-      } else {
-        for (int j = 1; j <= 2 * r; ++j) {
-          t = *reinterpret_cast<const float2*>(col + j * TW);
-          const float tp = P.taps[j <= r ? j : 2 * r - j];
-          b0 = fmaf(t.x, tp, b0);
-          b1 = fmaf(t.y, tp, b1);
-        }
-      }
-      const float* lc = Lt + (ly + r) * PW + r + px;
-      const float4 ab = *reinterpret_cast<const float4*>(AB + (ly * TW + px) * 2);
-      const Lab q0 = usm_on_lab<PLAIN>(lc[0], ab.x, ab.y, b0, P);
-      const Lab q1 = usm_on_lab<PLAIN>(lc[1], ab.z, ab.w, b1, P);
-      Px o0, o1;
-      if (!PLAIN && P.lab_io) {
-        o0 = Px{q0.L, q0.a, q0.b};
-        o1 = Px{q1.L, q1.a, q1.b};
-      } else {
-        o0 = lab_to_rgb(q0, P);
-        o1 = lab_to_rgb(q1, P);
-      }
-      usm_store_pair<OUT>(d, W, H, y0 + ly, x0 + px, finish<OUT, true>(o0, P), finish<OUT, true>(o1, P));
-    }
-    __syncthreads();  // the next tile's phase 1 overwrites the planes phase 3 has just read
+    cur = nxt;
   }
 }
 
@@ -278,6 +401,19 @@ static int usm_wg_per_cu() {
     return x >= 1 && x <= 16 ? x : 2;
   }();
   return v;
+}
+
+// Segment length limits (tiles).  Read at every launch so that tests can force multi-tile segments on
+// small images (SS_USM_SEG_MIN) and tuning runs can cap them (SS_USM_SEG_TILES).
+static int usm_seg_tiles_max() {
+  const char* e = getenv("SS_USM_SEG_TILES");
+  const int x = e ? atoi(e) : 0;
+  return x >= 1 ? x : 16;
+}
+static int usm_seg_tiles_min() {
+  const char* e = getenv("SS_USM_SEG_MIN");
+  const int x = e ? atoi(e) : 0;
+  return x >= 1 ? x : 1;
 }
 
 static size_t usm_lds_bytes(int r) {
@@ -294,15 +430,23 @@ static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  TileWalk T;
+  StripWalk T;
   T.tiles_x = (P.width + USM_TW - 1) / USM_TW;
   T.tiles_y = (P.height + USM_TH - 1) / USM_TH;
-  T.tiles_per_img = T.tiles_x * T.tiles_y;
-  T.n_tiles = (int64_t)T.tiles_per_img * batch;
-  // persistent workgroups: a multiple of 8 (one share per XCD), at most usm_wg_per_cu per CU
-  int64_t want = (T.n_tiles + 7) / 8 * 8;
-  const int64_t cap = (int64_t)256 * usm_wg_per_cu();
-  const unsigned blocks = (unsigned)(want < cap ? want : cap);
+  const int64_t cap = (int64_t)256 * usm_wg_per_cu();  // persistent workgroups
+  // segment length: long enough that the first tile's extra halo rows are noise, short enough that every
+  // workgroup gets many segments (load balance)
+  const int64_t tiles_total = (int64_t)T.tiles_x * T.tiles_y * batch;
+  int seg = (int)(tiles_total / (cap * 8));
+  if (seg < 1) seg = 1;
+  if (seg > usm_seg_tiles_max()) seg = usm_seg_tiles_max();
+  if (seg < usm_seg_tiles_min()) seg = usm_seg_tiles_min();
+  if (seg > T.tiles_y) seg = T.tiles_y;
+  if (R_T == 0 || ccm_needs_table<CCMC>) seg = 1;  // only the fast path carries rows between tiles
+  T.seg_tiles = seg;
+  T.segs_y = (T.tiles_y + seg - 1) / seg;
+  T.n_segments = (int64_t)T.tiles_x * T.segs_y * batch;
+  const unsigned blocks = (unsigned)(T.n_segments < cap ? T.n_segments : cap);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(USM_NT), lds, st, P, T, src, dst);
   return hipGetLastError();
 }

@@ -257,6 +257,22 @@ def test_config2_ccm_gain_usm_u16(swatches, shape, amount):
     assert diff.max() <= 1
 
 
+@pytest.mark.parametrize("seg_min", [2, 3, 16])
+@pytest.mark.parametrize("radius", [1.0, 2.0])
+def test_usm_rows_carried_between_tiles(swatches, monkeypatch, seg_min, radius):
+    """Tiles of one vertical segment hand their lower halo rows to the next tile instead of recomputing
+    them; SS_USM_SEG_MIN forces multi-tile segments on an image this small (7 x 4 tiles of 128 x 32)."""
+    M_T, M_R = swatches
+    monkeypatch.setenv("SS_USM_SEG_MIN", str(seg_min))
+    img = inputs.smooth_image(62, 230, 400)
+    imgs = np.stack([img, img[::-1].copy()])
+    got = run_chain_dev(imgs, ccm=fit(M_T, M_R), gains=[1.05], usm=(50.0, radius, 0.0), final_clip=True, out="f32")
+    for i in range(2):
+        c = np.clip(lv.colour_correction(imgs[i], M_T, M_R) * 1.05, 0, 1)
+        want = np.clip(oc.adjust_sharpen(c, 50.0, radius, 0.0), 0, 1)
+        assert np.max(np.abs(got[i] - want)) <= F32_TOL
+
+
 @pytest.mark.parametrize("radius,threshold", [(0.5, 0.0), (1.0, 3.0), (1.5, 0.0), (3.0, 1.0), (5.0, 0.0)])
 def test_usm_all_radii_f32(radius, threshold):
     img = inputs.smooth_image(61, 150, 210)
