@@ -32,6 +32,7 @@ struct ss_ctx {
   size_t ws_samples_bytes = 0;
   void* ws_small = nullptr;  // histograms, select state, partials
   size_t ws_small_bytes = 0;
+  uint32_t* usm_ticket = nullptr;  // segment counter of the unsharp-mask kernel's work queue
   // host path
   void* pinned[2] = {nullptr, nullptr};
   hipEvent_t pinned_free[2] = {nullptr, nullptr};
@@ -311,6 +312,12 @@ int ss_ctx_create(int device, ss_ctx** out_ctx) {
     return fail(nullptr, SS_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  e = hipMalloc(reinterpret_cast<void**>(&c->usm_ticket), 256);
+  if (e != hipSuccess) {
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return fail(nullptr, SS_ERR_NOMEM, "hipMalloc of the work-queue counter failed: %s", hipGetErrorString(e));
+  }
   hipEventCreate(&c->t0);
   hipEventCreate(&c->t1);
   *out_ctx = c;
@@ -323,6 +330,7 @@ void ss_ctx_destroy(ss_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->ws_samples) hipFree(c->ws_samples);
   if (c->ws_small) hipFree(c->ws_small);
+  if (c->usm_ticket) hipFree(c->usm_ticket);
   if (c->host_src) hipFree(c->host_src);
   if (c->host_dst) hipFree(c->host_dst);
   if (c->host_neg) hipFree(c->host_neg);
@@ -361,7 +369,7 @@ int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* 
   if (rc) return rc;
   if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
     return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
-  hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream)
+  hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->usm_ticket, c->stream)
                        : launch_chain(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream);
   if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return SS_OK;

@@ -81,14 +81,24 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
 // CCMC: CCM_LIN3 for the reference's 3-term correction, CCM_RUNTIME for everything else.
 //
 // Strip walk: the tile grid of every image is cut into vertical segments of `seg_tiles` tiles, one tile
-// wide.  A workgroup takes whole segments and walks each top to bottom.  Consecutive tiles of a segment
-// share 2r rows of halo: after a tile's phase 3 the bottom 2r rows of both LDS planes are moved to the top
-// (through registers, across the tile's closing barrier), so only the first tile of a segment computes
-// its upper halo.  Any assignment of segments to workgroups is correct; the order only affects speed.
+// wide.  A workgroup walks a segment top to bottom, then takes the next free segment off a device-side
+// ticket counter (workgroups that share a CU do not progress at the same speed, so a fixed deal would
+// leave the fast ones idle at the end).  Consecutive tiles of a segment share 2r rows of halo: after a
+// tile's phase 3 the bottom 2r rows of both LDS planes are moved to the top (through registers, across
+// the tile's closing barrier), so only the first tile of a segment computes its upper halo.  Any
+// assignment of segments to workgroups is correct; the order only affects speed.
 struct StripWalk {
   int tiles_x, tiles_y, seg_tiles, segs_y;
-  int64_t n_segments;  // whole batch
+  uint32_t n_segments;  // whole batch
+  uint32_t* ticket;     // next free segment; the launcher sets it to gridDim.x before every launch
 };
+
+#ifdef SS_USM_TRACE  // timing experiment: per-workgroup start / end clock and tile count
+__device__ unsigned long long ss_usm_trace_buf[1024][4];
+extern "C" int ss_debug_usm_trace(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ss_usm_trace_buf), sizeof(ss_usm_trace_buf));
+}
+#endif
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>
 __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const StripWalk T,
@@ -96,11 +106,16 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   constexpr int TW = USM_TW, TH = USM_TH, NT = USM_NT;
   extern __shared__ __attribute__((aligned(16))) float S[];
   __shared__ float4 M[ccm_needs_table<CCMC> ? SS_MAX_CCM_TERMS : 1];
+  __shared__ uint32_t next_seg;
   if constexpr (ccm_needs_table<CCMC>) {
     stage_ccm(P, M, threadIdx.x, NT);
     __syncthreads();
   }
 
+#ifdef SS_USM_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+  unsigned trace_tiles = 0;
+#endif
   const int r = R_T ? R_T : P.usm_r;
   const int PWv = TW + 2 * r;     // slots per LDS row that hold data
   const int PW = (PWv + 3) & ~3;  // row pitch in floats (rows stay 16-byte aligned)
@@ -127,34 +142,36 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   constexpr int CARRY_MAX = (2 * SS_MAX_USM_RADIUS * ((USM_TW + 2 * SS_MAX_USM_RADIUS + 3) / 4 + USM_TW / 4) + NT - 1) / NT;
   constexpr int CARRY = R_T ? (2 * R_T * ((TW + 2 * R_T + 3) / 4 + TW / 4) + NT - 1) / NT : CARRY_MAX;
   const int carry_lt = 2 * r * (PW / 4), carry_n = carry_lt + 2 * r * (TW / 4);
+  int carry_from[CARRY], carry_to[CARRY];  // float offsets into S of the vectors this thread moves
+#pragma unroll
+  for (int k = 0; k < CARRY; ++k) {
+    int i = tid + k * NT;
+    if (i >= carry_n) i = carry_n - 1;
+    const bool in_lt = i < carry_lt;
+    carry_to[k] = in_lt ? 4 * i : PH * PW + 4 * (i - carry_lt);
+    carry_from[k] = carry_to[k] + (in_lt ? TH * PW : TH * TW);
+  }
 
-  // ---- the walk: (segment, tile) positions of this workgroup, flattened so that the pixel loads of the
+  // ---- the walk: tile positions of this workgroup, flattened so that the pixel loads of the
   // NEXT tile can be issued while the current tile is still in its phases 2 and 3 ----
   struct TilePos {
-    int64_t seg;
-    int img, x0, ty, ty_begin, ty_end;
-    bool valid;
+    uint32_t seg;
+    int img, x0, ty, ty_end;
+    bool valid, first;
   };
-  auto seg_pos = [&](int64_t seg) -> TilePos {
+  auto seg_pos = [&](uint32_t seg) -> TilePos {
     TilePos t;
     t.seg = seg;
     t.valid = seg < T.n_segments;
     const int per_img = T.tiles_x * T.segs_y;
     t.img = (int)(seg / per_img);
-    const int s_in = (int)(seg - (int64_t)t.img * per_img);
+    const int s_in = (int)(seg - (uint32_t)t.img * per_img);
     const int sy = s_in / T.tiles_x;
     t.x0 = (s_in - sy * T.tiles_x) * TW;
-    t.ty_begin = sy * T.seg_tiles;
-    t.ty_end = t.ty_begin + T.seg_tiles < T.tiles_y ? t.ty_begin + T.seg_tiles : T.tiles_y;
-    t.ty = t.ty_begin;
+    t.ty = sy * T.seg_tiles;
+    t.ty_end = t.ty + T.seg_tiles < T.tiles_y ? t.ty + T.seg_tiles : T.tiles_y;
+    t.first = true;
     return t;
-  };
-  auto next_pos = [&](TilePos t) -> TilePos {
-    if (t.ty + 1 < t.ty_end) {
-      t.ty += 1;
-      return t;
-    }
-    return seg_pos(t.seg + gridDim.x);
   };
   // source pixel index of LDS slot (ly, lx) of the tile at (x0, y0)
   auto slot_src = [&](int x0, int y0, bool interior, int ly, int lx) -> uint32_t {
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
     return x0 >= r && y0 >= r && x0 + TW + r <= W && y0 + TH + r <= H;
   };
   // Fast path: compile-time radius and a colour correction small enough to unroll.  The other kernels walk
-  // their slots with plain loops and never carry rows between tiles (the launcher gives them 1-tile segments).
+  // their slots with plain loops and never carry rows between tiles (the launcher clears StripWalk::carry for them).
   constexpr bool PREFETCH = R_T != 0 && !ccm_needs_table<CCMC>;
   F3 v[MAIN + 1];
   // issue every pixel load of a tile's new rows
@@ -191,75 +208,23 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
     }
   };
 
+  // The loop is rotated by one phase: an iteration issues the pixel loads of tile i+1 (`pend`), runs phases
+  // 2 and 3 of tile i (`cur`) while they are in flight, then phase 1 of tile i+1.  The loaded pixels are
+  // produced and consumed inside one iteration, so no register copy (and no wait on the loads) is needed
+  // at the loop edge.
+  constexpr int DEFER = PREFETCH ? (R_T + ROWS_PER_PASS - 1) / ROWS_PER_PASS + 1 : 1;
+  float2 late_ab[DEFER];
   int cur_img = -1;
   ImgParams ip;
-  TilePos cur = seg_pos(blockIdx.x);
-  if (cur.valid) issue_loads(cur);
-  while (cur.valid) {
-    const TilePos nxt = next_pos(cur);
-    {
-      const int img = cur.img, x0 = cur.x0, ty = cur.ty;
-      if (img != cur_img) {
-        ip = load_img_params(P, img);
-        cur_img = img;
-      }
-      const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * P.n_px * 3);
-      char* d = reinterpret_cast<char*>(dst) + (size_t)img * P.n_px * 3 * OutTraits<OUT>::BYTES;
-      const int y0 = ty * TH;
-      const bool first = ty == cur.ty_begin;
-      const bool interior = is_interior(x0, y0);
-
-      // ---- phase 1: stages 1-4 + RGB -> Lab, Ln to LDS for every slot, (a, b) for the tile's own pixels ----
-      auto slot_lab = [&](const F3 px) -> Lab {
-#ifdef SS_ABL_NO_P1  // timing experiment: phase 1 without its arithmetic
-        return Lab{px.x * 100.0f, px.y, px.z};
-#else
-        const Px p = front<CCMC, true, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M);
-        if (!PLAIN && P.lab_io) return Lab{p.r, p.g, p.b};
-        return rgb_to_lab(p, P);
-#endif
-      };
-      auto slot_compute = [&](const F3 px, int ly, int lx) {
-        const Lab q = slot_lab(px);
-        Lt[ly * PW + lx] = q.L * 0.01f;
-        const int cy = ly - r, cx = lx - r;
-        if ((unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW) {
-          *reinterpret_cast<float2*>(AB + (cy * TW + cx) * 2) = make_float2(q.a, q.b);
-        }
-      };
-      if (first) {  // upper halo rows [0, 2r): only the first tile of a segment has to compute them
-        for (int idx = tid; idx < 2 * r * PWv; idx += NT) {
-          const int ly = idx / PWv, lx = idx - ly * PWv;
-          slot_compute(s[slot_src(x0, y0, interior, ly, lx)], ly, lx);
-        }
-      }
-      // (a, b) of the last r new rows belong to the NEXT tile's first r rows: they wait in registers until
-      // this tile's phase 3 is done with the plane
-      constexpr int DEFER = PREFETCH ? (R_T + ROWS_PER_PASS - 1) / ROWS_PER_PASS + 1 : 1;
-      float2 late_ab[DEFER];
-      if constexpr (PREFETCH) {
-#pragma unroll
-        for (int k = 0; k < MAIN; ++k) {
-          const int ln = ROWS_PER_PASS * k + m_row;  // new-row number, AB row r + ln
-          const Lab q = slot_lab(v[k]);
-          Lt[(2 * r + ln) * PW + r + m_col] = q.L * 0.01f;
-          if (k < MAIN - DEFER) {
-            *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
-          } else {
-            if (r + ln < TH) *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
-            late_ab[k - (MAIN - DEFER)] = make_float2(q.a, q.b);
-          }
-        }
-        if (s_on) Lt[(2 * r + s_row) * PW + s_lx] = slot_lab(v[MAIN]).L * 0.01f;
-      } else {
-        for (int idx = tid; idx < n_new; idx += NT) {
-          const int ly = idx / PWv, lx = idx - ly * PWv;
-          slot_compute(s[slot_src(x0, y0, interior, ly + 2 * r, lx)], ly + 2 * r, lx);
-        }
-      }
-      USM_SYNC();
-      // the registers of this tile's pixels are free again: fetch the next tile's while phases 2 and 3 run
-      if (nxt.valid) issue_loads(nxt);
+  TilePos cur, pend = seg_pos(blockIdx.x);
+  cur.valid = false;
+  for (;;) {
+    if (pend.valid) issue_loads(pend);
+    if (cur.valid) {
+      const int x0 = cur.x0, y0 = cur.ty * TH;
+      const bool first = cur.first;
+      const bool more = pend.valid && !pend.first;  // the next tile continues this segment
+      char* d = reinterpret_cast<char*>(dst) + (size_t)cur.img * P.n_px * 3 * OutTraits<OUT>::BYTES;
 
       // ---- phase 2: row pass over the rows phase 1 has just written ----
       const int row_begin = first ? 0 : 2 * r;
@@ -352,31 +317,20 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #endif
       }
 
-      // ---- carry the bottom 2r rows of both planes to the top for the next tile of the segment ----
+      // ---- carry the bottom 2r rows of both planes to the top for the next tile of the column ----
       // read before the barrier (phase 3 only reads the planes), write after it (nobody reads any more)
-      float4 carry[CARRY];
-      const bool more = nxt.valid && nxt.seg == cur.seg;
-      if (more) {
-#pragma unroll
-        for (int k = 0; k < CARRY; ++k) {
-          const int i = tid + k * NT;
-          if (i < carry_lt) {
-            carry[k] = *reinterpret_cast<const float4*>(Lt + TH * PW + 4 * i);
-          } else if (i < carry_n) {
-            carry[k] = *reinterpret_cast<const float4*>(Ht + TH * TW + 4 * (i - carry_lt));
-          }
-        }
+      // (every thread reads: lanes beyond the carried range re-read its last vector and write nothing)
+      static_assert(CARRY <= 2 || !PREFETCH, "two vectors per thread cover the compile-time radii");
+      float4 carry0, carry1;
+      if constexpr (PREFETCH) {
+        carry0 = *reinterpret_cast<const float4*>(S + carry_from[0]);
+        if constexpr (CARRY > 1) carry1 = *reinterpret_cast<const float4*>(S + carry_from[1]);
       }
       USM_SYNC();  // phase 3 is done with the planes
-      if (more) {
-#pragma unroll
-        for (int k = 0; k < CARRY; ++k) {
-          const int i = tid + k * NT;
-          if (i < carry_lt) {
-            *reinterpret_cast<float4*>(Lt + 4 * i) = carry[k];
-          } else if (i < carry_n) {
-            *reinterpret_cast<float4*>(Ht + 4 * (i - carry_lt)) = carry[k];
-          }
+      if (PREFETCH && more) {
+        if (tid < carry_n) *reinterpret_cast<float4*>(S + carry_to[0]) = carry0;
+        if constexpr (CARRY > 1) {
+          if (tid + NT < carry_n) *reinterpret_cast<float4*>(S + carry_to[1]) = carry1;
         }
         if constexpr (PREFETCH) {
 #pragma unroll
@@ -389,8 +343,94 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         // here, and its own barrier orders these writes before any read
       }
     }
-    cur = nxt;
+    if (!pend.valid) break;
+    cur = pend;
+    {
+      // the last tile of a segment draws the workgroup's next segment; the ticket travels through LDS at
+      // the barrier that closes phase 1
+      const bool last_of_seg = cur.ty + 1 >= cur.ty_end;
+      uint32_t drawn = 0;
+      if (last_of_seg && tid == 0) drawn = atomicAdd(T.ticket, 1u);
+      const int img = cur.img, x0 = cur.x0, y0 = cur.ty * TH;
+      if (img != cur_img) {
+        ip = load_img_params(P, img);
+        cur_img = img;
+      }
+      const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * P.n_px * 3);
+      const bool first = cur.first;
+      const bool interior = is_interior(x0, y0);
+
+      // ---- phase 1: stages 1-4 + RGB -> Lab, Ln to LDS for every slot, (a, b) for the tile's own pixels ----
+      auto slot_lab = [&](const F3 px) -> Lab {
+#ifdef SS_ABL_NO_P1  // timing experiment: phase 1 without its arithmetic
+        return Lab{px.x * 100.0f, px.y, px.z};
+#else
+        const Px p = front<CCMC, true, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M);
+        if (!PLAIN && P.lab_io) return Lab{p.r, p.g, p.b};
+        return rgb_to_lab(p, P);
+#endif
+      };
+      auto slot_compute = [&](const F3 px, int ly, int lx) {
+        const Lab q = slot_lab(px);
+        Lt[ly * PW + lx] = q.L * 0.01f;
+        const int cy = ly - r, cx = lx - r;
+        if ((unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW) {
+          *reinterpret_cast<float2*>(AB + (cy * TW + cx) * 2) = make_float2(q.a, q.b);
+        }
+      };
+      if (first) {  // upper halo rows [0, 2r): only a first tile has to compute them
+        for (int idx = tid; idx < 2 * r * PWv; idx += NT) {
+          const int ly = idx / PWv, lx = idx - ly * PWv;
+          slot_compute(s[slot_src(x0, y0, interior, ly, lx)], ly, lx);
+        }
+      }
+      // (a, b) of the last r new rows belong to the NEXT tile's first r rows: they wait in registers until
+      // this tile's phase 3 is done with the plane
+      if constexpr (PREFETCH) {
+#pragma unroll
+        for (int k = 0; k < MAIN; ++k) {
+          const int ln = ROWS_PER_PASS * k + m_row;  // new-row number, AB row r + ln
+          const Lab q = slot_lab(v[k]);
+          Lt[(2 * r + ln) * PW + r + m_col] = q.L * 0.01f;
+          if (k < MAIN - DEFER) {
+            *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
+          } else {
+            if (r + ln < TH) *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
+            late_ab[k - (MAIN - DEFER)] = make_float2(q.a, q.b);
+          }
+        }
+        if (s_on) Lt[(2 * r + s_row) * PW + s_lx] = slot_lab(v[MAIN]).L * 0.01f;
+      } else {
+        for (int idx = tid; idx < n_new; idx += NT) {
+          const int ly = idx / PWv, lx = idx - ly * PWv;
+          slot_compute(s[slot_src(x0, y0, interior, ly + 2 * r, lx)], ly + 2 * r, lx);
+        }
+      }
+      if (last_of_seg && tid == 0) next_seg = drawn;
+      USM_SYNC();
+      if (last_of_seg) {
+        pend = seg_pos(next_seg);
+      } else {
+        pend.ty += 1;
+        pend.first = false;
+      }
+    }
+#ifdef SS_USM_TRACE
+    ++trace_tiles;
+#endif
   }
+#ifdef SS_USM_TRACE
+  if (tid == 0 && blockIdx.x < 1024) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    ss_usm_trace_buf[blockIdx.x][0] = trace_t0;
+    ss_usm_trace_buf[blockIdx.x][1] = wall_clock64();
+    ss_usm_trace_buf[blockIdx.x][2] = trace_tiles;
+    ss_usm_trace_buf[blockIdx.x][3] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // Workgroups launched per CU (two fit in LDS at r <= 6); SS_USM_WG_PER_CU overrides it for tuning.
@@ -403,17 +443,17 @@ static int usm_wg_per_cu() {
   return v;
 }
 
-// Segment length limits (tiles).  Read at every launch so that tests can force multi-tile segments on
-// small images (SS_USM_SEG_MIN) and tuning runs can cap them (SS_USM_SEG_TILES).
-static int usm_seg_tiles_max() {
+// Segment length (tiles) and an upper limit on the number of workgroups.  Read at every launch so that tests
+// can force long segments and few workgroups on small images, and tuning runs can vary the length.
+static int usm_seg_tiles() {
   const char* e = getenv("SS_USM_SEG_TILES");
   const int x = e ? atoi(e) : 0;
-  return x >= 1 ? x : 16;
+  return x >= 1 ? x : 8;
 }
-static int usm_seg_tiles_min() {
-  const char* e = getenv("SS_USM_SEG_MIN");
+static int64_t usm_max_wg() {
+  const char* e = getenv("SS_USM_MAX_WG");
   const int x = e ? atoi(e) : 0;
-  return x >= 1 ? x : 1;
+  return x >= 1 ? x : INT32_MAX;
 }
 
 static size_t usm_lds_bytes(int r) {
@@ -422,7 +462,8 @@ static size_t usm_lds_bytes(int r) {
 }
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>
-static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* src, void* dst, hipStream_t st) {
+static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* src, void* dst, uint32_t* ticket,
+                                  hipStream_t st) {
   const size_t lds = usm_lds_bytes(P.usm_r);
   auto kern = usm_kernel<R_T, CCMC, OUT, PLAIN>;
   if (lds > 64 * 1024) {  // sticky per device and kernel; cheap enough to repeat
@@ -433,38 +474,40 @@ static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* s
   StripWalk T;
   T.tiles_x = (P.width + USM_TW - 1) / USM_TW;
   T.tiles_y = (P.height + USM_TH - 1) / USM_TH;
-  const int64_t cap = (int64_t)256 * usm_wg_per_cu();  // persistent workgroups
-  // segment length: long enough that the first tile's extra halo rows are noise, short enough that every
-  // workgroup gets many segments (load balance)
-  const int64_t tiles_total = (int64_t)T.tiles_x * T.tiles_y * batch;
-  int seg = (int)(tiles_total / (cap * 8));
-  if (seg < 1) seg = 1;
-  if (seg > usm_seg_tiles_max()) seg = usm_seg_tiles_max();
-  if (seg < usm_seg_tiles_min()) seg = usm_seg_tiles_min();
+  int64_t cap = (int64_t)256 * usm_wg_per_cu();  // persistent workgroups
+  if (cap > usm_max_wg()) cap = usm_max_wg();
+  // segment length: long enough that the first tile's extra halo rows are noise, short enough that the
+  // workgroups finish close together
+  int seg = usm_seg_tiles();
   if (seg > T.tiles_y) seg = T.tiles_y;
-  if (R_T == 0 || ccm_needs_table<CCMC>) seg = 1;  // only the fast path carries rows between tiles
+  if (R_T == 0 || ccm_needs_table<CCMC>) seg = 1;  // only the fast path hands rows from tile to tile
   T.seg_tiles = seg;
   T.segs_y = (T.tiles_y + seg - 1) / seg;
-  T.n_segments = (int64_t)T.tiles_x * T.segs_y * batch;
-  const unsigned blocks = (unsigned)(T.n_segments < cap ? T.n_segments : cap);
+  const int64_t n_segments = (int64_t)T.tiles_x * T.segs_y * batch;
+  if (n_segments > INT32_MAX) return hipErrorInvalidValue;
+  T.n_segments = (uint32_t)n_segments;
+  T.ticket = ticket;
+  const unsigned blocks = (unsigned)(n_segments < cap ? n_segments : cap);
+  hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ticket), (int)blocks, 1, st);
+  if (me != hipSuccess) return me;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(USM_NT), lds, st, P, T, src, dst);
   return hipGetLastError();
 }
 
 template <int R_T, int CCMC, bool PLAIN>
 static hipError_t launch_usm_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                 hipStream_t st) {
+                                 uint32_t* ticket, hipStream_t st) {
   switch (out_kind) {
     case SS_OUT_F32_LINEAR:
-      return launch_usm_one<R_T, CCMC, SS_OUT_F32_LINEAR, PLAIN>(P, batch, src, dst, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_F32_LINEAR, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_F32_SRGB:
-      return launch_usm_one<R_T, CCMC, SS_OUT_F32_SRGB, PLAIN>(P, batch, src, dst, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_F32_SRGB, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_U16_SRGB:
-      return launch_usm_one<R_T, CCMC, SS_OUT_U16_SRGB, PLAIN>(P, batch, src, dst, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_U16_SRGB, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_U8_SRGB:
-      return launch_usm_one<R_T, CCMC, SS_OUT_U8_SRGB, PLAIN>(P, batch, src, dst, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_U8_SRGB, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_U8_LINEAR:
-      return launch_usm_one<R_T, CCMC, SS_OUT_U8_LINEAR, PLAIN>(P, batch, src, dst, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_U8_LINEAR, PLAIN>(P, batch, src, dst, ticket, st);
     default:
       return hipErrorInvalidValue;
   }
@@ -472,20 +515,21 @@ static hipError_t launch_usm_out(const ChainParams& P, int batch, int out_kind, 
 
 template <int R_T>
 static hipError_t launch_usm_ccm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                 hipStream_t st) {
+                                 uint32_t* ticket, hipStream_t st) {
   const bool lin3 = P.ccm_kind != SS_CCM_NONE && P.ccm_terms == 3;
   // the worker's chart path without further adjustments: CCM, one gain stage, sharpen
   const bool plain = lin3 && !P.neg && P.n_gain == 1 && !P.sh && !P.lab_io && P.usm_thr == 0.0f;
-  if (plain) return launch_usm_out<R_T, CCM_LIN3, true>(P, batch, out_kind, src, dst, st);
-  if (lin3) return launch_usm_out<R_T, CCM_LIN3, false>(P, batch, out_kind, src, dst, st);
-  return launch_usm_out<R_T, CCM_RUNTIME, false>(P, batch, out_kind, src, dst, st);
+  if (plain) return launch_usm_out<R_T, CCM_LIN3, true>(P, batch, out_kind, src, dst, ticket, st);
+  if (lin3) return launch_usm_out<R_T, CCM_LIN3, false>(P, batch, out_kind, src, dst, ticket, st);
+  return launch_usm_out<R_T, CCM_RUNTIME, false>(P, batch, out_kind, src, dst, ticket, st);
 }
 
-hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {
+hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, uint32_t* ticket,
+                      hipStream_t st) {
   if (P.usm_r < 1 || P.usm_r > SS_MAX_USM_RADIUS) return hipErrorInvalidValue;
-  if (P.usm_r == 3) return launch_usm_ccm<3>(P, batch, out_kind, src, dst, st);
-  if (P.usm_r == 6) return launch_usm_ccm<6>(P, batch, out_kind, src, dst, st);
-  return launch_usm_ccm<0>(P, batch, out_kind, src, dst, st);
+  if (P.usm_r == 3) return launch_usm_ccm<3>(P, batch, out_kind, src, dst, ticket, st);
+  if (P.usm_r == 6) return launch_usm_ccm<6>(P, batch, out_kind, src, dst, ticket, st);
+  return launch_usm_ccm<0>(P, batch, out_kind, src, dst, ticket, st);
 }
 
 }  // namespace ss

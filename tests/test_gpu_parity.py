@@ -257,13 +257,16 @@ def test_config2_ccm_gain_usm_u16(swatches, shape, amount):
     assert diff.max() <= 1
 
 
-@pytest.mark.parametrize("seg_min", [2, 3, 16])
+@pytest.mark.parametrize("max_wg,seg_tiles", [(1, 8), (3, 3), (7, 16), (512, 2)])
 @pytest.mark.parametrize("radius", [1.0, 2.0])
-def test_usm_rows_carried_between_tiles(swatches, monkeypatch, seg_min, radius):
-    """Tiles of one vertical segment hand their lower halo rows to the next tile instead of recomputing
-    them; SS_USM_SEG_MIN forces multi-tile segments on an image this small (7 x 4 tiles of 128 x 32)."""
+def test_usm_rows_carried_between_tiles(swatches, monkeypatch, max_wg, seg_tiles, radius):
+    """Consecutive tiles of a vertical segment hand their lower halo rows to the next tile instead of
+    recomputing them, and workgroups draw further segments from a ticket counter.  SS_USM_SEG_TILES sets the
+    segment length and SS_USM_MAX_WG limits the workgroups, so that on this small batch (2 images of 4 x 8
+    tiles, 128 x 32 pixels each) every workgroup walks several multi-tile segments."""
     M_T, M_R = swatches
-    monkeypatch.setenv("SS_USM_SEG_MIN", str(seg_min))
+    monkeypatch.setenv("SS_USM_MAX_WG", str(max_wg))
+    monkeypatch.setenv("SS_USM_SEG_TILES", str(seg_tiles))
     img = inputs.smooth_image(62, 230, 400)
     imgs = np.stack([img, img[::-1].copy()])
     got = run_chain_dev(imgs, ccm=fit(M_T, M_R), gains=[1.05], usm=(50.0, radius, 0.0), final_clip=True, out="f32")
