@@ -14,6 +14,9 @@ LIB = os.path.join(HERE, "libscanspace_hip.so")
 SOURCES = ["chain.hip", "usm.hip", "stats.hip", "api.hip"]
 HEADERS = ["ss_device.h", "ss_internal.h", os.path.join("..", "..", "include", "scanspace.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+# Per-file flags.  usm.hip packs its pair arithmetic explicitly; the SLP vectoriser's own pairs in phase 1
+# need aligned register pairs, and the copies it inserts for them wait on the prefetched pixel loads.
+FILE_FLAGS = {"usm.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -44,7 +47,7 @@ def build(force=False, verbose=False, extra_flags=()):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(s), []), *extra_flags, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{r.stderr}")

@@ -142,16 +142,6 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   constexpr int CARRY_MAX = (2 * SS_MAX_USM_RADIUS * ((USM_TW + 2 * SS_MAX_USM_RADIUS + 3) / 4 + USM_TW / 4) + NT - 1) / NT;
   constexpr int CARRY = R_T ? (2 * R_T * ((TW + 2 * R_T + 3) / 4 + TW / 4) + NT - 1) / NT : CARRY_MAX;
   const int carry_lt = 2 * r * (PW / 4), carry_n = carry_lt + 2 * r * (TW / 4);
-  int carry_from[CARRY], carry_to[CARRY];  // float offsets into S of the vectors this thread moves
-#pragma unroll
-  for (int k = 0; k < CARRY; ++k) {
-    int i = tid + k * NT;
-    if (i >= carry_n) i = carry_n - 1;
-    const bool in_lt = i < carry_lt;
-    carry_to[k] = in_lt ? 4 * i : PH * PW + 4 * (i - carry_lt);
-    carry_from[k] = carry_to[k] + (in_lt ? TH * PW : TH * TW);
-  }
-
   // ---- the walk: tile positions of this workgroup, flattened so that the pixel loads of the
   // NEXT tile can be issued while the current tile is still in its phases 2 and 3 ----
   struct TilePos {
@@ -278,29 +268,14 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       USM_SYNC();
 
       // ---- phase 3: column pass, mask logic, Lab -> sRGB, encode, store ----
-      for (int pair = tid; pair < TH * TW / 2; pair += NT) {
-        const int ly = pair >> 6, px = (pair & 63) * 2;
-        const float* col = Ht + ly * TW + px;
-        float2 t = *reinterpret_cast<const float2*>(col);
-        v2f blur = v2f{t.x, t.y} * P.taps[0];
-        if constexpr (R_T != 0) {
-#pragma unroll
-          for (int j = 1; j <= 2 * R_T; ++j) {
-            t = *reinterpret_cast<const float2*>(col + j * TW);
-            blur = mad<v2f>(v2f{t.x, t.y}, tap_at<R_T>(P, j), blur);
-          }
-        } else {
-          for (int j = 1; j <= 2 * r; ++j) {
-            t = *reinterpret_cast<const float2*>(col + j * TW);
-            blur = mad<v2f>(v2f{t.x, t.y}, P.taps[j <= r ? j : 2 * r - j], blur);
-          }
-        }
-        const float* lc = Lt + (ly + r) * PW + r + px;
+      // one pixel pair at a time: everything after the blur
+      auto pair_out = [&](int ly, int px, v2f blur) {
+        const float2 lc = *reinterpret_cast<const float2*>(Lt + (ly + r) * PW + r + px);
         const float4 ab = *reinterpret_cast<const float4*>(AB + (ly * TW + px) * 2);
 #ifdef SS_ABL_NO_P3  // timing experiment: phase 3 without its arithmetic
-        Px2 o = Px2{blur, v2f{lc[0], lc[1]} + v2f{ab.x, ab.z}, v2f{ab.y, ab.w}};
+        Px2 o = Px2{blur, v2f{lc.x, lc.y} + v2f{ab.x, ab.z}, v2f{ab.y, ab.w}};
 #else
-        const Lab2 q = usm_on_lab<PLAIN, v2f>(v2f{lc[0], lc[1]}, v2f{ab.x, ab.z}, v2f{ab.y, ab.w}, blur, P);
+        const Lab2 q = usm_on_lab<PLAIN, v2f>(v2f{lc.x, lc.y}, v2f{ab.x, ab.z}, v2f{ab.y, ab.w}, blur, P);
         Px2 o;
         if (!PLAIN && P.lab_io) {
           o = Px2{q.L, q.a, q.b};
@@ -315,12 +290,74 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #else
         usm_store_pair<OUT>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
 #endif
+      };
+      if constexpr (R_T != 0) {
+        // a thread owns one pixel-pair column and RUN consecutive rows: the RUN + 2r row-filtered values it
+        // needs are read once, all reads in flight together, and every output reuses 2r of them
+        constexpr int RUN = TH / (NT / (TW / 2));
+        static_assert(RUN * (NT / (TW / 2)) == TH, "runs must tile the rows");
+        const int px = (tid & (TW / 2 - 1)) * 2, ly0 = (tid / (TW / 2)) * RUN;
+        // rows are read in batches (all reads of a batch in flight together) and folded at once into every
+        // output they belong to, so only the batch and the RUN accumulators occupy registers
+        constexpr int ROWS = RUN + 2 * R_T, BATCH = 8;
+        v2f blur[RUN];
+#pragma unroll
+        for (int j0 = 0; j0 < ROWS; j0 += BATCH) {
+          v2f win[BATCH];
+#pragma unroll
+          for (int j = j0; j < j0 + BATCH && j < ROWS; ++j) {
+            const float2 t = *reinterpret_cast<const float2*>(Ht + (ly0 + j) * TW + px);
+            win[j - j0] = v2f{t.x, t.y};
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = j0; j < j0 + BATCH && j < ROWS; ++j) {
+#pragma unroll
+            for (int q = 0; q < RUN; ++q) {
+              const int tap = j - q;  // row j is tap `tap` of output q
+              if (tap == 0) blur[q] = win[j - j0] * P.taps[0];
+              if (tap > 0 && tap <= 2 * R_T) blur[q] = mad<v2f>(win[j - j0], tap_at<R_T>(P, tap), blur[q]);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < RUN; ++q) {
+          pair_out(ly0 + q, px, blur[q]);
+          __builtin_amdgcn_sched_barrier(0);  // one pair's arithmetic at a time keeps the register count down
+        }
+      } else {
+        for (int pair = tid; pair < TH * TW / 2; pair += NT) {
+          const int ly = pair >> 6, px = (pair & 63) * 2;
+          const float* col = Ht + ly * TW + px;
+          float2 t = *reinterpret_cast<const float2*>(col);
+          v2f blur = v2f{t.x, t.y} * P.taps[0];
+          for (int j = 1; j <= 2 * r; ++j) {
+            t = *reinterpret_cast<const float2*>(col + j * TW);
+            blur = mad<v2f>(v2f{t.x, t.y}, P.taps[j <= r ? j : 2 * r - j], blur);
+          }
+          pair_out(ly, px, blur);
+        }
       }
 
       // ---- carry the bottom 2r rows of both planes to the top for the next tile of the column ----
       // read before the barrier (phase 3 only reads the planes), write after it (nobody reads any more)
       // (every thread reads: lanes beyond the carried range re-read its last vector and write nothing)
       static_assert(CARRY <= 2 || !PREFETCH, "two vectors per thread cover the compile-time radii");
+      // float offsets into S of the vectors this thread moves; derived from an opaque copy of the thread
+      // index so that they are recomputed per tile instead of occupying registers across the whole loop
+      int carry_from[CARRY], carry_to[CARRY];
+      {
+        int t_op = tid;
+        asm volatile("" : "+v"(t_op));
+#pragma unroll
+        for (int k = 0; k < CARRY; ++k) {
+          int i = t_op + k * NT;
+          if (i >= carry_n) i = carry_n - 1;
+          const bool in_lt = i < carry_lt;
+          carry_to[k] = in_lt ? 4 * i : PH * PW + 4 * (i - carry_lt);
+          carry_from[k] = carry_to[k] + (in_lt ? TH * PW : TH * TW);
+        }
+      }
       float4 carry0, carry1;
       if constexpr (PREFETCH) {
         carry0 = *reinterpret_cast<const float4*>(S + carry_from[0]);

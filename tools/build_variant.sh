@@ -7,7 +7,7 @@ name=$1; shift
 mkdir -p ../variants build/$name
 for f in chain usm stats api; do
   if [ "$f" = usm ] || [ ! -f build/$f.o ]; then
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value "$@" -c $f.hip -o build/$name/$f.o &
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -fno-slp-vectorize "$@" -c $f.hip -o build/$name/$f.o &
   else
     cp build/$f.o build/$name/$f.o
   fi
