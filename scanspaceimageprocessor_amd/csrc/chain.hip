@@ -114,7 +114,10 @@ static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind
     const uint64_t groups = (uint64_t)P.n_px / G;
     uint64_t blocks = (groups + 256 * K - 1) / (256 * K);
     if (blocks < 1) blocks = 1;
-    if (blocks > 4096) blocks = 4096;
+    // one or two trips per workgroup stream best; kernels that stage a coefficient table in LDS per
+    // workgroup amortise that over more trips
+    const uint64_t cap = ccm_needs_table<CCMC> ? 4096 : 32768;
+    if (blocks > cap) blocks = cap;
     return dim3((unsigned)blocks, (unsigned)batch, 1);
   };
   switch (out_kind) {
