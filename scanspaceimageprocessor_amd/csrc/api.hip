@@ -33,6 +33,8 @@ struct ss_ctx {
   void* ws_small = nullptr;  // histograms, select state, partials
   size_t ws_small_bytes = 0;
   uint32_t* usm_ticket = nullptr;  // segment counter of the unsharp-mask kernel's work queue
+  void* ws_stage = nullptr;        // float32 images between the two passes of a staged chain
+  size_t ws_stage_bytes = 0;
   // host path
   void* pinned[2] = {nullptr, nullptr};
   hipEvent_t pinned_free[2] = {nullptr, nullptr};
@@ -282,9 +284,58 @@ int check_ctx(ss_ctx* c) {
   return SS_OK;
 }
 
+
+// Unsharp mask behind a colour correction of more than 3 terms: the fused tile kernel only carries the
+// 3-term matrix (larger expansions in it cost more registers than a tile kernel has), so the chain runs as
+// two launches per group of images: pointwise {negative inversion, colour correction} into a float32
+// staging buffer, then the tile kernel {gains, shadows/highlights, unsharp mask, encode} from there.
+// The staging buffer holds as many images as fit in kChainStageBytes (at least one); SS_CHAIN_STAGE_BYTES
+// overrides the size (tests use it to force several groups on small batches).
+constexpr size_t kChainStageBytes = (size_t)1 << 30;
+
+size_t chain_stage_bytes() {
+  const char* e = getenv("SS_CHAIN_STAGE_BYTES");
+  const long long x = e ? atoll(e) : 0;
+  return x > 0 ? (size_t)x : kChainStageBytes;
+}
+
+int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, const float* src_dev, void* dst_dev) {
+  const size_t image_bytes = (size_t)P.n_px * 3 * sizeof(float);
+  const size_t by_size = chain_stage_bytes() / image_bytes;
+  int group = by_size > (size_t)d->batch ? d->batch : (int)by_size;
+  if (group < 1) group = 1;
+  if (group > d->batch) group = d->batch;
+  int rc = grow(c, &c->ws_stage, &c->ws_stage_bytes, (size_t)group * image_bytes);
+  if (rc) return rc;
+  const size_t out_image_bytes = (size_t)P.n_px * out_bytes_per_px(d->out_kind);
+  for (int first = 0; first < d->batch; first += group) {
+    const int n = d->batch - first < group ? d->batch - first : group;
+    ChainParams A = P;  // stages 1-2
+    A.usm = 0;
+    A.n_gain = 0;
+    A.sh = 0;
+    A.lab_io = 0;
+    A.final_clip = 0;
+    if (A.neg_dev) A.neg_dev += (size_t)first * SS_NEG_PARAM_STRIDE;
+    ChainParams B = P;  // stages 3-7
+    B.neg = 0;
+    B.neg_dev = nullptr;
+    B.ccm_kind = SS_CCM_NONE;
+    B.ccm_terms = 0;
+    if (B.gain0_dev) B.gain0_dev += first;
+    hipError_t e = launch_chain(A, n, SS_OUT_F32_LINEAR, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, c->stream);
+    if (e == hipSuccess)
+      e = launch_usm(B, n, d->out_kind, (const float*)c->ws_stage, (char*)dst_dev + (size_t)first * out_image_bytes,
+                     c->usm_ticket, c->stream);
+    if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  }
+  return SS_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
 
 const char* ss_version(void) { return "scanspace-hip 0.1 (gfx950)"; }
 
@@ -331,6 +382,7 @@ void ss_ctx_destroy(ss_ctx* c) {
   if (c->ws_samples) hipFree(c->ws_samples);
   if (c->ws_small) hipFree(c->ws_small);
   if (c->usm_ticket) hipFree(c->usm_ticket);
+  if (c->ws_stage) hipFree(c->ws_stage);
   if (c->host_src) hipFree(c->host_src);
   if (c->host_dst) hipFree(c->host_dst);
   if (c->host_neg) hipFree(c->host_neg);
@@ -369,6 +421,7 @@ int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* 
   if (rc) return rc;
   if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
     return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
+  if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3) return run_staged_usm(c, d, P, src_dev, dst_dev);
   hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->usm_ticket, c->stream)
                        : launch_chain(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream);
   if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));

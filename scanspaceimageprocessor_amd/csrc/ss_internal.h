@@ -12,6 +12,7 @@ namespace ss {
 // Pointwise fused chain (stages 1-4, 6, 7) over `batch` images.
 hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st);
 // Fused chain with the unsharp mask (stage 5): tile + halo recompute, separable blur in LDS.
+// Colour correction: none or the 3-term matrix only (callers run larger expansions as a pointwise pass first).
 // `ticket`: one uint32 of device memory owned by the caller; launches that share it must be stream-ordered
 hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, uint32_t* ticket,
                       hipStream_t st);

@@ -78,7 +78,7 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
 }
 
 // R_T : compile-time blur radius (3 <-> sigma 1, 6 <-> sigma 2), 0 = runtime radius P.usm_r.
-// CCMC: CCM_LIN3 for the reference's 3-term correction, CCM_RUNTIME for everything else.
+// CCMC: CCM_LIN3 for the reference's 3-term correction, CCM_NONE for chains without one.
 //
 // Strip walk: the tile grid of every image is cut into vertical segments of `seg_tiles` tiles, one tile
 // wide.  A workgroup walks a segment top to bottom, then takes the next free segment off a device-side
@@ -558,7 +558,9 @@ static hipError_t launch_usm_ccm(const ChainParams& P, int batch, int out_kind, 
   const bool plain = lin3 && !P.neg && P.n_gain == 1 && !P.sh && !P.lab_io && P.usm_thr == 0.0f;
   if (plain) return launch_usm_out<R_T, CCM_LIN3, true>(P, batch, out_kind, src, dst, ticket, st);
   if (lin3) return launch_usm_out<R_T, CCM_LIN3, false>(P, batch, out_kind, src, dst, ticket, st);
-  return launch_usm_out<R_T, CCM_RUNTIME, false>(P, batch, out_kind, src, dst, ticket, st);
+  // colour corrections with more terms run as a pointwise pass of their own in front (see ss_chain_run)
+  if (P.ccm_kind != SS_CCM_NONE) return hipErrorInvalidValue;
+  return launch_usm_out<R_T, CCM_NONE, false>(P, batch, out_kind, src, dst, ticket, st);
 }
 
 hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, uint32_t* ticket,

@@ -11,6 +11,7 @@ import pytest
 
 from conftest import golden_input
 from gpu_util import DeviceBuffer, fit, run_chain_dev
+from scanspaceimageprocessor_amd.chain import make_desc
 from oracle import chain as oc
 from oracle import inputs
 from oracle import leaves as lv
@@ -181,7 +182,6 @@ def test_config3_negative_then_ccm_batch(swatches):
     dst = DeviceBuffer(ctx, imgs.nbytes)
     try:
         ctx.negative_params(src.ptr, 600, 900, 3, 0.005, 0.995, True, params.ptr, None)
-        from scanspaceimageprocessor_amd.chain import make_desc
         desc = make_desc(600, 900, 3, neg=True, neg_params_dev=params.ptr, ccm=fit(M_T, M_R), gains=[1.0], out="f32")
         ctx.chain_run(desc, src.ptr, dst.ptr)
         ctx.sync()
@@ -288,6 +288,56 @@ def test_usm_of_constant_image_is_identity_after_round_trip():
     img = np.full((70, 140, 3), 0.5, np.float32)
     got = run_chain_dev(img, usm=(80.0, 2.0, 0.0), out="f32")[0]
     assert np.max(np.abs(got - 0.5)) <= 2e-6
+
+
+@pytest.mark.parametrize("stage_bytes", [None, 1, 2 * 150 * 220 * 12])
+@pytest.mark.parametrize("method,kw,negative", [("Cheung 2004", {"terms": 5}, True), ("Cheung 2004", {"terms": 10}, True),
+                                                ("Finlayson 2015", {"degree": 3}, False)])
+def test_usm_behind_larger_colour_corrections(swatches, monkeypatch, stage_bytes, method, kw, negative):
+    """Corrections of more than 3 terms run as a pointwise pass into a staging buffer in front of the tile
+    kernel; SS_CHAIN_STAGE_BYTES sizes that buffer so that the 3 images go through in 1, 2 or 3 groups.
+    Per-image inversion parameters and gain factors (device tables) must follow the groups.  (The root
+    polynomial is fed positives: its roots have unbounded slope at the zeros an inversion produces, where
+    float32 and float64 inputs cannot agree to 1e-5.)"""
+    M_T, M_R = swatches
+    if stage_bytes is not None:
+        monkeypatch.setenv("SS_CHAIN_STAGE_BYTES", str(stage_bytes))
+    h, w = 150, 220
+    make = inputs.negative_image if negative else inputs.linear_image
+    imgs = np.stack([make(50 + i, h, w) for i in range(3)])
+    factors = np.array([0.9, 1.0, 1.25], np.float32)
+    ctx = default_context()
+    src = DeviceBuffer.from_array(ctx, imgs)
+    params = DeviceBuffer(ctx, 3 * 32)
+    gains = DeviceBuffer.from_array(ctx, factors)
+    dst = DeviceBuffer(ctx, imgs.nbytes)
+    try:
+        if negative:
+            ctx.negative_params(src.ptr, h, w, 3, 0.05, 0.995, True, params.ptr, None)
+        desc = make_desc(h, w, 3, neg=True if negative else None, neg_params_dev=params.ptr if negative else None,
+                         ccm=fit(M_T, M_R, method=method, **kw), gains=[1.0], gain0_dev=gains.ptr,
+                         usm=(60.0, 2.0, 0.0), final_clip=True, out="f32")
+        ctx.chain_run(desc, src.ptr, dst.ptr)
+        ctx.sync()
+        got = dst.to_array(imgs.shape, np.float32)
+    finally:
+        src.free(); params.free(); gains.free(); dst.free()
+    for i in range(3):
+        pos = oc.invert_negative_auto(imgs[i], 0.05, 0.995, legacy=True) if negative else imgs[i]
+        c = np.clip(lv.colour_correction(pos, M_T, M_R, method=method, **kw) * float(factors[i]), 0, 1)
+        want = np.clip(oc.adjust_sharpen(c, 60.0, 2.0, 0.0), 0, 1)
+        assert np.max(np.abs(got[i] - want)) <= 3 * F32_TOL
+
+
+@pytest.mark.parametrize("radius", [1.0, 2.0])
+def test_no_chart_path_all_adjustments(radius):
+    """The worker's no-chart path: exposure, shadows/highlights and sharpen with no colour correction."""
+    img = inputs.linear_image(77, 130, 260)
+    got = run_chain_dev(img, gains=[2.0 ** 0.3], sh=(0.4 / 70, -0.3 * 1.3, 7.0), usm=(45.0, radius, 0.0),
+                        final_clip=True, out="f32")[0]
+    want = oc.apply_all_adjustments(img, exposure=0.3, shadows=0.4, highlights=-0.3, sharpen_amount=45.0,
+                                    sharpen_radius=radius)
+    assert np.max(np.abs(got - np.clip(want, 0, 1))) <= F32_TOL
 
 
 @pytest.mark.parametrize("degree", [2, 3])

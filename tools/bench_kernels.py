@@ -31,7 +31,7 @@ def swatches():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--configs", default="1,2,2b,3,4,4b")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -65,7 +65,7 @@ def main():
 
     todo = args.configs.split(",")
     H, W, B = 4000, 6000, args.batch
-    if any(c in todo for c in ("1", "2", "2b", "3", "1u16", "1u8")):
+    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "5", "5b", "5c")):
         img = images(H, W, B)
         out = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
     if "1" in todo:
@@ -86,6 +86,16 @@ def main():
     if "2r1" in todo:
         d = make_desc(H, W, B, ccm=lin3, gains=[1.1], usm=(50.0, 1.0, 0.0), final_clip=True, out="u16")
         report("2r1 ccm3+gain+usm(r1,a50)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "5" in todo:  # the worker's no-chart path with every adjustment on: exposure, S/H, sharpen radius 1
+        d = make_desc(H, W, B, gains=[1.2], sh=(0.5 / 70, -0.5 * 1.3, 7.0), usm=(40.0, 1.0, 0.0), final_clip=True, out="u16")
+        report("5  gain+S/H+usm(r1,a40)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "5b" in todo:  # chart path + S/H + sharpen: 3-term CCM, not the plain specialisation
+        d = make_desc(H, W, B, ccm=lin3, gains=[1.1], sh=(0.5 / 70, -0.5 * 1.3, 7.0), usm=(40.0, 2.0, 1.0), final_clip=True, out="u16")
+        report("5b ccm3+gain+S/H+usm(r2,a40,t1)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "5c" in todo:  # table-driven colour correction in front of the unsharp mask
+        ccm = matrix_colour_correction(M_T, M_R, method="Finlayson 2015", degree=3)
+        d = make_desc(H, W, B, ccm=ccm, gains=[1.1], usm=(50.0, 2.0, 0.0), final_clip=True, out="u16")
+        report("5c rootpoly(d3)+gain+usm(r2,a50)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
     if "3" in todo:
         neg = images(H, W, B, negative=True)
         params = torch.empty((B, _lib.SS_NEG_PARAM_STRIDE), dtype=torch.float32, device=dev)
