@@ -180,6 +180,76 @@ __device__ __forceinline__ PxT<V> lab_to_rgb(const LabT<V> q, const ChainParams&
   return o;
 }
 
+// ---- Lab edits on RGB data without the round-trip error -----------------------------------------
+// The reference edits L (and scales a, b) between _rgb_to_lab and _lab_to_rgb in float64, where an
+// unedited pixel comes back exactly.  In float32 the literal round trip loses ~1e-7 absolute per linear
+// channel (X, Y, Z ~ 0.5 cancel to a dark channel through the inverse matrix), which two successive sRGB
+// encodes amplify 167-fold near black - several 16-bit steps.  So the edit is applied as a difference:
+//   linear' = linear + M_inv * (g(f + df) - g(f)),   g = lab_finv,  f = (fx, fy, fz) of the pixel,
+// whose error is proportional to the size of the edit, not to the size of XYZ.
+
+template <class V>
+struct LabFT {
+  V fx, fy, fz;
+};
+
+// (fx, fy, fz) of linear RGB
+template <class V>
+__device__ __forceinline__ LabFT<V> linear_to_labf(const PxT<V> lin, const ChainParams& P) {
+  LabFT<V> f;
+  f.fx = lab_f(mad<V>(P.m_fwd[0], lin.r, mad<V>(P.m_fwd[1], lin.g, lin.b * P.m_fwd[2])));
+  f.fy = lab_f(mad<V>(P.m_fwd[3], lin.r, mad<V>(P.m_fwd[4], lin.g, lin.b * P.m_fwd[5])));
+  f.fz = lab_f(mad<V>(P.m_fwd[6], lin.r, mad<V>(P.m_fwd[7], lin.g, lin.b * P.m_fwd[8])));
+  return f;
+}
+
+__device__ __forceinline__ bool all_lanes(bool p) { return __all(p) != 0; }
+__device__ __forceinline__ bool both(bool p) { return p; }
+__device__ __forceinline__ bool both(v2i p) { return (p.x & p.y) != 0; }
+__device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ v2f vmin(v2f a, v2f b) { return v2f{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+
+// g(f + d) - g(f) on the cubic segment of g: d (3 f (f + d) + d^2), free of cancellation
+template <class V>
+__device__ __forceinline__ V finv_delta_cubic(V f, V d) {
+  return d * mad<V>(d, d, (f * (f + d)) * 3.0f);
+}
+// ... and anywhere.  g is the cube with its tangent line at T = 6/29 substituted below T:
+// g(f) = f^3 - e(f), e(f) = min(f - T, 0)^2 (f + 2T).  e is small (< 0.018) and smooth, so its plain
+// difference adds no error that matters, and no select is needed.
+template <class V>
+__device__ __forceinline__ V finv_tangent_gap(V f) {
+  const V m = vmin(f - 24.0f / 116.0f, (V)(0.0f));
+  return (m * m) * (f + 48.0f / 116.0f);
+}
+template <class V>
+__device__ __forceinline__ V finv_delta_any(V f, V d) {
+  return finv_delta_cubic(f, d) - (finv_tangent_gap(f + d) - finv_tangent_gap(f));
+}
+
+// clip(encode(linear + M_inv * (g(f + df) - g(f)))): what _lab_to_rgb returns for the edited pixel
+template <class V>
+__device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy, const V dfz,
+                                              const ChainParams& P) {
+  V dx, dy, dz;
+  // wave-uniform choice: almost every wave has all its pixels on the cubic segment
+  const V lowest = vmin(vmin(vmin(f.fx, f.fy), f.fz), vmin(vmin(f.fx + dfx, f.fy + dfy), f.fz + dfz));
+  if (all_lanes(both(lowest > (V)(24.0f / 116.0f)))) {
+    dx = finv_delta_cubic(f.fx, dfx);
+    dy = finv_delta_cubic(f.fy, dfy);
+    dz = finv_delta_cubic(f.fz, dfz);
+  } else {
+    dx = finv_delta_any(f.fx, dfx);
+    dy = finv_delta_any(f.fy, dfy);
+    dz = finv_delta_any(f.fz, dfz);
+  }
+  PxT<V> o;
+  o.r = clamp01(srgb_encode(mad<V>(P.m_inv[0], dx, mad<V>(P.m_inv[1], dy, mad<V>(P.m_inv[2], dz, lin.r)))));
+  o.g = clamp01(srgb_encode(mad<V>(P.m_inv[3], dx, mad<V>(P.m_inv[4], dy, mad<V>(P.m_inv[5], dz, lin.g)))));
+  o.b = clamp01(srgb_encode(mad<V>(P.m_inv[6], dx, mad<V>(P.m_inv[7], dy, mad<V>(P.m_inv[8], dz, lin.b)))));
+  return o;
+}
+
 // ---- colour correction ---------------------------------------------------------------------
 
 // dot product of T expansion terms with the staged table M[t] = {cR, cG, cB, 0} (LDS, broadcast reads)
@@ -399,13 +469,20 @@ __device__ __forceinline__ ImgParams load_img_params(const ChainParams& P, int i
 
 // ---- stage 4: shadows / highlights on Lab (editingTools.py:508-536) --------------------------
 
+// total adjustment in L units (editingTools.py:518-522)
 template <class V>
-__device__ __forceinline__ LabT<V> sh_on_lab(LabT<V> q, const ChainParams& P) {
-  const V Ln = q.L * 0.01f;
+__device__ __forceinline__ V sh_total(const V L, const ChainParams& P) {
+  const V Ln = L * 0.01f;
   V total = (V)(0.0f);
   if (P.sh_hs != 0.0f) total = (hw_exp2(Ln * P.sh_log2f) - 1.0f) * P.sh_hs;
   if (P.sh_ss != 0.0f) total = mad<V>(hw_exp2((1.0f - Ln) * P.sh_log2f) - 1.0f, P.sh_ss, total);
-  total = total * 100.0f;
+  return total * 100.0f;
+}
+
+// Lab in, Lab out: the reference's LAB-input branch
+template <class V>
+__device__ __forceinline__ LabT<V> sh_on_lab(LabT<V> q, const ChainParams& P) {
+  const V total = sh_total(q.L, P);
   q.L = clampf(q.L + total, 0.0f, 100.0f);
   if (P.sh_chroma) {
     const V cs = 1.0f - clampf(vabs(total) * (0.05f / 20.0f), 0.0f, 0.2f);
@@ -413,6 +490,27 @@ __device__ __forceinline__ LabT<V> sh_on_lab(LabT<V> q, const ChainParams& P) {
     q.b = q.b * cs;
   }
   return q;
+}
+
+__device__ __forceinline__ float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ v2f med3(v2f x, v2f lo, v2f hi) { return v2f{med3(x.x, lo.x, hi.x), med3(x.y, lo.y, hi.y)}; }
+
+// RGB (sRGB-encoded, as the reference assumes) in and out: _rgb_to_lab, the edit, _lab_to_rgb
+template <class V>
+__device__ __forceinline__ PxT<V> sh_on_rgb(const PxT<V> p, const ChainParams& P) {
+  const PxT<V> lin{srgb_decode(p.r), srgb_decode(p.g), srgb_decode(p.b)};
+  const LabFT<V> f = linear_to_labf(lin, P);
+  const V L = mad<V>(f.fy, 116.0f, -16.0f);
+  const V total = sh_total(L, P);
+  // clip(L + total, 0, 100) - L, exactly
+  const V dfy = med3(total, -L, 100.0f - L) * (1.0f / 116.0f);
+  V dfx = dfy, dfz = dfy;
+  if (P.sh_chroma) {
+    const V shrink = clampf(vabs(total) * (0.05f / 20.0f), 0.0f, 0.2f);  // a' - a = -a * shrink, a/500 = fx - fy
+    dfx = dfy - (f.fx - f.fy) * shrink;
+    dfz = dfy + (f.fy - f.fz) * shrink;
+  }
+  return shifted_rgb(lin, f, dfx, dfy, dfz, P);
 }
 
 // ---- stages 1-4 --------------------------------------------------------------------------------
@@ -456,7 +554,7 @@ __device__ __forceinline__ PxT<V> front(PxT<V> p, const ChainParams& P, const Im
         const LabT<V> q = sh_on_lab(LabT<V>{p.r, p.g, p.b}, P);
         p = PxT<V>{q.L, q.a, q.b};
       } else {
-        p = lab_to_rgb(sh_on_lab(rgb_to_lab(p, P), P), P);
+        p = sh_on_rgb(p, P);
       }
     }
   }
@@ -486,6 +584,34 @@ __device__ __forceinline__ LabT<V> usm_on_lab(const V Ln, const V a, const V b, 
     o.b = b;
   }
   return o;
+}
+
+// The same edit on RGB data: `lin` = decoded (linear) pixel, Ln = L/100 of it, Lb = blurred Ln.
+// Returns what _lab_to_rgb gives for the sharpened pixel (sRGB-encoded, clipped).
+template <bool PLAIN = false, class V = float>
+__device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const V Lb, const ChainParams& P) {
+  LabFT<V> f;
+  f.fy = mad<V>(Ln, 100.0f / 116.0f, 16.0f / 116.0f);
+  f.fx = lab_f(mad<V>(P.m_fwd[0], lin.r, mad<V>(P.m_fwd[1], lin.g, lin.b * P.m_fwd[2])));
+  f.fz = lab_f(mad<V>(P.m_fwd[6], lin.r, mad<V>(P.m_fwd[7], lin.g, lin.b * P.m_fwd[8])));
+  V um = Ln - Lb;
+  if (!PLAIN && P.usm_thr > 0.0f) {
+    const V es = vabs(um);
+    um = um * (es > (V)(P.usm_thr) ? (V)(1.0f) : es * P.usm_inv_thr);
+  }
+  const V hm = Ln > (V)(0.9f) ? mad<V>(Ln - 0.9f, -10.0f, 1.0f) : (V)(1.0f);
+  const V sm = Ln < (V)(0.1f) ? Ln * 10.0f : (V)(1.0f);
+  const V ad = clampf(hm * sm, 0.1f, 1.0f);
+  // clip(Ln + um * amount * ad, 0, 1) - Ln, exactly; L = 100 Ln = 116 fy - 16
+  const V dfy = med3((um * P.usm_amount_scaled) * ad, -Ln, 1.0f - Ln) * (100.0f / 116.0f);
+  V dfx = dfy, dfz = dfy;
+  if (P.usm_chroma) {
+    const V boost = mad<V>(vabs(um), P.usm_chroma_k, 1.0f);
+    const V a = (f.fx - f.fy) * 500.0f, b = (f.fy - f.fz) * 200.0f;
+    dfx = mad<V>(clampf(a * boost, -127.0f, 127.0f) - a, 1.0f / 500.0f, dfy);
+    dfz = mad<V>(clampf(b * boost, -127.0f, 127.0f) - b, -1.0f / 200.0f, dfy);
+  }
+  return shifted_rgb(lin, f, dfx, dfy, dfz, P);
 }
 
 // ---- stages 6-7: final clip, encoding, quantisation -------------------------------------------

@@ -1,17 +1,18 @@
 // Fused correction chain WITH the unsharp mask (stage 5) for gfx950.
 //
-// A 512-thread workgroup owns one 128 x 32 pixel tile at a time and walks a list of tiles.
-//   phase 1  every thread walks the tile plus its halo of r pixels (flat index, lanes along x, so
-//            each wave-instruction is a contiguous run of 12-byte pixels), runs stages 1-4 and the
-//            RGB -> Lab conversion, and leaves Ln = L/100 of every slot and (a, b) of the tile's own
-//            pixels in LDS.  Halo pixels are recomputed rather than exchanged: 1.5x the per-pixel
-//            front work at r = 6, no intermediate plane in HBM, no inter-workgroup dependency.
-//   phase 2  row pass of the separable Gaussian (cv2 filters rows first), 4 outputs per thread from a
-//            sliding register window fed by ds_read_b128, into a second LDS plane.
-//   phase 3  column pass for the tile's pixels (pairs, ds_read_b64), mask logic, Lab -> sRGB, final
-//            encoding, quantisation, one 12-byte store per lane for 16-bit output.
-// Algorithmic HBM traffic: 12 B/px in + 12 / 6 / 3 B/px out; halo re-reads are served by L2.
-// LDS per workgroup at r = 6: (44 x 140 + 44 x 128 + 32 x 128 x 2) x 4 B = 79,936 B -> two workgroups
+// A 512-thread workgroup owns one 128 x 24 pixel tile at a time and walks vertical runs of tiles.
+//   phase 1  stages 1-4, sRGB decode and the lightness Ln = L/100 for the tile's new rows plus r halo
+//            columns on either side (lanes along x, so each wave-instruction is a contiguous run of
+//            12-byte pixels).  Ln of every slot and the decoded (linear) RGB of the tile's own pixels
+//            go to LDS.  Halo pixels are recomputed rather than exchanged: no intermediate plane in
+//            HBM, no inter-workgroup dependency.
+//   phase 2  row pass of the separable Gaussian (cv2 filters rows first), 4 outputs per thread from
+//            ds_read_b128 windows, into a second LDS plane.
+//   phase 3  column pass for the tile's pixels (pairs), mask logic, the Lab edit applied to the linear
+//            pixel as a difference (see ss_device.h), encode, final encoding, quantisation, one 12-byte
+//            store per lane for 16-bit output.
+// Algorithmic HBM traffic: 12 B/px in + 12 / 6 / 3 B/px out.
+// LDS per workgroup at r = 6: (36 x 140 + 36 x 128 + 3 x 24 x 128) x 4 B = 75,456 B -> two workgroups
 // (16 waves) per CU.
 
 #include "ss_internal.h"
@@ -19,7 +20,7 @@
 namespace ss {
 
 constexpr int USM_TW = 128;  // tile width: 64 lanes x 2 adjacent pixels
-constexpr int USM_TH = 32;   // tile height
+constexpr int USM_TH = 24;   // tile height
 #ifndef SS_USM_NT
 #define SS_USM_NT 512
 #endif
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   const int PH = TH + 2 * r;
   float* __restrict__ Lt = S;             // [PH][PW]  Ln of tile + halo
   float* __restrict__ Ht = Lt + PH * PW;  // [PH][TW]  row-filtered Ln
-  float* __restrict__ AB = Ht + PH * TW;  // [TH][TW][2] a, b of the tile's pixels
+  float* __restrict__ C0 = Ht + PH * TW;  // [3][TH][TW] the tile's pixels: linear R, G, B (L, a, b for Lab data)
+  constexpr int CP = TH * TW;             // plane pitch
   const int W = P.width, H = P.height;
   const int tid = threadIdx.x;
   // Rows every tile computes itself: LDS rows [2r, PH) ("new rows", TH of them: image rows y0+r ... y0+TH+r-1).
@@ -134,10 +136,29 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   constexpr int MAIN = TH / ROWS_PER_PASS;      // 8 main slots per thread
   static_assert(NT % TW == 0 && TH % (NT / TW) == 0, "tile shape must divide the workgroup");
   static_assert(2 * (R_T ? R_T : 1) * TH <= NT, "one side slot per thread at most");
-  const int m_row = tid / TW, m_col = tid - m_row * TW;  // main slots: new row 4k + m_row, tile column m_col
-  const int s_row = tid / (2 * r), s_j = tid - s_row * (2 * r);
-  const int s_lx = s_j < r ? s_j : s_j + TW;             // side slot: new row s_row, LDS column s_lx
-  const bool s_on = tid < 2 * r * TH;
+  // The slot coordinates are cheap to derive and expensive to keep: every phase derives its own from an opaque
+  // copy of the thread index, so that the compiler cannot hoist them (and the LDS addresses built on them)
+  // out of the tile loop into registers that would then spill.
+  auto fresh_tid = [&]() -> int {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  struct Lane {
+    int m_row, m_col;  // main slots: new row 4k + m_row, tile column m_col
+    int s_row, s_lx;   // side slot: new row s_row, LDS column s_lx
+    bool s_on;
+  };
+  auto lane_of = [&](int t) -> Lane {
+    Lane l;
+    l.m_row = t / TW;
+    l.m_col = t - l.m_row * TW;
+    l.s_row = t / (2 * r);
+    const int s_j = t - l.s_row * (2 * r);
+    l.s_lx = s_j < r ? s_j : s_j + TW;
+    l.s_on = t < 2 * r * TH;
+    return l;
+  };
   // float4 moves per thread for the carried rows: 2r rows of Lt (PW floats) and of Ht (TW floats)
   constexpr int CARRY_MAX = (2 * SS_MAX_USM_RADIUS * ((USM_TW + 2 * SS_MAX_USM_RADIUS + 3) / 4 + USM_TW / 4) + NT - 1) / NT;
   constexpr int CARRY = R_T ? (2 * R_T * ((TW + 2 * R_T + 3) / 4 + TW / 4) + NT - 1) / NT : CARRY_MAX;
@@ -190,10 +211,11 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #pragma unroll
       for (int k = 0; k <= MAIN; ++k) v[k] = F3{(float)(tid + k) * 1e-4f, (float)k * 1e-2f, 0.5f};
 #else
+      const Lane l = lane_of(fresh_tid());
 #pragma unroll
       for (int k = 0; k < MAIN; ++k)
-        v[k] = s[slot_src(t.x0, y0, interior, 2 * r + ROWS_PER_PASS * k + m_row, r + m_col)];
-      if (s_on) v[MAIN] = s[slot_src(t.x0, y0, interior, 2 * r + s_row, s_lx)];
+        v[k] = s[slot_src(t.x0, y0, interior, 2 * r + ROWS_PER_PASS * k + l.m_row, r + l.m_col)];
+      if (l.s_on) v[MAIN] = s[slot_src(t.x0, y0, interior, 2 * r + l.s_row, l.s_lx)];
 #endif
     }
   };
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   // produced and consumed inside one iteration, so no register copy (and no wait on the loads) is needed
   // at the loop edge.
   constexpr int DEFER = PREFETCH ? (R_T + ROWS_PER_PASS - 1) / ROWS_PER_PASS + 1 : 1;
-  float2 late_ab[DEFER];
+  F3 late_c[DEFER];
   int cur_img = -1;
   ImgParams ip;
   TilePos cur, pend = seg_pos(blockIdx.x);
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #ifdef SS_ABL_NO_P2
       for (int item = tid; item < 0; item += NT) {
 #else
-      for (int item = tid; item < n_items; item += NT) {
+      for (int item = fresh_tid(); item < n_items; item += NT) {
 #endif
         const int row = row_begin + (item >> 5), q = item & 31;
         const float* base = Lt + row * PW + 4 * q;
@@ -271,18 +293,21 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       // one pixel pair at a time: everything after the blur
       auto pair_out = [&](int ly, int px, v2f blur) {
         const float2 lc = *reinterpret_cast<const float2*>(Lt + (ly + r) * PW + r + px);
-        const float4 ab = *reinterpret_cast<const float4*>(AB + (ly * TW + px) * 2);
+        const float* cq = C0 + ly * TW + px;
+        const float2 c0 = *reinterpret_cast<const float2*>(cq), c1 = *reinterpret_cast<const float2*>(cq + CP),
+                     c2 = *reinterpret_cast<const float2*>(cq + 2 * CP);
+        const v2f Ln = v2f{lc.x, lc.y};
 #ifdef SS_ABL_NO_P3  // timing experiment: phase 3 without its arithmetic
-        Px2 o = Px2{blur, v2f{lc.x, lc.y} + v2f{ab.x, ab.z}, v2f{ab.y, ab.w}};
+        Px2 o = Px2{blur + v2f{c0.x, c0.y}, Ln + v2f{c1.x, c1.y}, v2f{c2.x, c2.y}};
 #else
-        const Lab2 q = usm_on_lab<PLAIN, v2f>(v2f{lc.x, lc.y}, v2f{ab.x, ab.z}, v2f{ab.y, ab.w}, blur, P);
         Px2 o;
         if (!PLAIN && P.lab_io) {
+          const Lab2 q = usm_on_lab<PLAIN, v2f>(Ln, v2f{c1.x, c1.y}, v2f{c2.x, c2.y}, blur, P);
           o = Px2{q.L, q.a, q.b};
         } else {
-          o = lab_to_rgb(q, P);
+          o = usm_on_rgb<PLAIN, v2f>(Px2{v2f{c0.x, c0.y}, v2f{c1.x, c1.y}, v2f{c2.x, c2.y}}, Ln, blur, P);
         }
-        // lab_to_rgb leaves [0,1]; the LAB branch has no final clip: either way the clip stage is a no-op here
+        // the sharpened pixel is in [0,1]; the LAB branch has no final clip: either way the clip stage is a no-op here
         o = finish<OUT, true, v2f>(o, P);
 #endif
 #ifdef SS_ABL_NO_STORE
@@ -296,7 +321,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         // needs are read once, all reads in flight together, and every output reuses 2r of them
         constexpr int RUN = TH / (NT / (TW / 2));
         static_assert(RUN * (NT / (TW / 2)) == TH, "runs must tile the rows");
-        const int px = (tid & (TW / 2 - 1)) * 2, ly0 = (tid / (TW / 2)) * RUN;
+        const int t3 = fresh_tid();
+        const int px = (t3 & (TW / 2 - 1)) * 2, ly0 = (t3 / (TW / 2)) * RUN;
         // rows are read in batches (all reads of a batch in flight together) and folded at once into every
         // output they belong to, so only the batch and the RUN accumulators occupy registers
         constexpr int ROWS = RUN + 2 * R_T, BATCH = 8;
@@ -370,13 +396,19 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
           if (tid + NT < carry_n) *reinterpret_cast<float4*>(S + carry_to[1]) = carry1;
         }
         if constexpr (PREFETCH) {
+          const Lane l = lane_of(fresh_tid());
 #pragma unroll
           for (int k = MAIN - DEFER; k < MAIN; ++k) {
-            const int ab_row = r + ROWS_PER_PASS * k + m_row - TH;  // row in the next tile's plane
-            if (ab_row >= 0) *reinterpret_cast<float2*>(AB + (ab_row * TW + m_col) * 2) = late_ab[k - (MAIN - DEFER)];
+            const int c_row = r + ROWS_PER_PASS * k + l.m_row - TH;  // row in the next tile's planes
+            if (c_row >= 0) {
+              float* q = C0 + c_row * TW + l.m_col;
+              q[0] = late_c[k - (MAIN - DEFER)].x;
+              q[CP] = late_c[k - (MAIN - DEFER)].y;
+              q[2 * CP] = late_c[k - (MAIN - DEFER)].z;
+            }
           }
         }
-        // the next tile's phase 1 writes Lt rows [2r, PH) and AB rows [r, TH): disjoint from what is written
+        // the next tile's phase 1 writes Lt rows [2r, PH) and plane rows [r, TH): disjoint from what is written
         // here, and its own barrier orders these writes before any read
       }
     }
@@ -397,23 +429,34 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       const bool first = cur.first;
       const bool interior = is_interior(x0, y0);
 
-      // ---- phase 1: stages 1-4 + RGB -> Lab, Ln to LDS for every slot, (a, b) for the tile's own pixels ----
-      auto slot_lab = [&](const F3 px) -> Lab {
+      // ---- phase 1: stages 1-4, decode, Ln to LDS for every slot, the pixel itself for the tile's own ----
+      struct Slot {
+        float Ln;
+        F3 c;  // what phase 3 needs of the pixel: linear RGB, or (L, a, b) when the data is Lab
+      };
+      auto slot_eval = [&](const F3 px, bool need_c) -> Slot {
 #ifdef SS_ABL_NO_P1  // timing experiment: phase 1 without its arithmetic
-        return Lab{px.x * 100.0f, px.y, px.z};
+        return Slot{px.x, px};
 #else
         const Px p = front<CCMC, true, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M);
-        if (!PLAIN && P.lab_io) return Lab{p.r, p.g, p.b};
-        return rgb_to_lab(p, P);
+        if (!PLAIN && P.lab_io) return Slot{p.r * 0.01f, F3{p.r, p.g, p.b}};
+        const float r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
+        const float fy = lab_f(fmaf(P.m_fwd[3], r, fmaf(P.m_fwd[4], g, b * P.m_fwd[5])));
+        return Slot{fmaf(fy, 116.0f, -16.0f) * 0.01f, F3{r, g, b}};
 #endif
       };
+      auto plane_write = [&](int cy, int cx, const F3 c) {
+        float* q = C0 + cy * TW + cx;
+        q[0] = c.x;
+        q[CP] = c.y;
+        q[2 * CP] = c.z;
+      };
       auto slot_compute = [&](const F3 px, int ly, int lx) {
-        const Lab q = slot_lab(px);
-        Lt[ly * PW + lx] = q.L * 0.01f;
         const int cy = ly - r, cx = lx - r;
-        if ((unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW) {
-          *reinterpret_cast<float2*>(AB + (cy * TW + cx) * 2) = make_float2(q.a, q.b);
-        }
+        const bool own = (unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW;
+        const Slot q = slot_eval(px, own);
+        Lt[ly * PW + lx] = q.Ln;
+        if (own) plane_write(cy, cx, q.c);
       };
       if (first) {  // upper halo rows [0, 2r): only a first tile has to compute them
         for (int idx = tid; idx < 2 * r * PWv; idx += NT) {
@@ -421,22 +464,23 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
           slot_compute(s[slot_src(x0, y0, interior, ly, lx)], ly, lx);
         }
       }
-      // (a, b) of the last r new rows belong to the NEXT tile's first r rows: they wait in registers until
-      // this tile's phase 3 is done with the plane
+      // the pixels of the last r new rows belong to the NEXT tile's first r plane rows: they wait in
+      // registers until this tile's phase 3 is done with the planes
       if constexpr (PREFETCH) {
+        const Lane l = lane_of(fresh_tid());
 #pragma unroll
         for (int k = 0; k < MAIN; ++k) {
-          const int ln = ROWS_PER_PASS * k + m_row;  // new-row number, AB row r + ln
-          const Lab q = slot_lab(v[k]);
-          Lt[(2 * r + ln) * PW + r + m_col] = q.L * 0.01f;
+          const int ln = ROWS_PER_PASS * k + l.m_row;  // new-row number, plane row r + ln
+          const Slot q = slot_eval(v[k], true);
+          Lt[(2 * r + ln) * PW + r + l.m_col] = q.Ln;
           if (k < MAIN - DEFER) {
-            *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
+            plane_write(r + ln, l.m_col, q.c);
           } else {
-            if (r + ln < TH) *reinterpret_cast<float2*>(AB + ((r + ln) * TW + m_col) * 2) = make_float2(q.a, q.b);
-            late_ab[k - (MAIN - DEFER)] = make_float2(q.a, q.b);
+            if (r + ln < TH) plane_write(r + ln, l.m_col, q.c);
+            late_c[k - (MAIN - DEFER)] = q.c;
           }
         }
-        if (s_on) Lt[(2 * r + s_row) * PW + s_lx] = slot_lab(v[MAIN]).L * 0.01f;
+        if (l.s_on) Lt[(2 * r + l.s_row) * PW + l.s_lx] = slot_eval(v[MAIN], false).Ln;
       } else {
         for (int idx = tid; idx < n_new; idx += NT) {
           const int ly = idx / PWv, lx = idx - ly * PWv;
@@ -495,7 +539,7 @@ static int64_t usm_max_wg() {
 
 static size_t usm_lds_bytes(int r) {
   const int PW = (USM_TW + 2 * r + 3) & ~3, PH = USM_TH + 2 * r;
-  return (size_t)(PH * PW + PH * USM_TW + USM_TH * USM_TW * 2) * sizeof(float);
+  return (size_t)(PH * PW + PH * USM_TW + USM_TH * USM_TW * 3) * sizeof(float);
 }
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>

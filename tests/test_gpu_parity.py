@@ -262,8 +262,8 @@ def test_config2_ccm_gain_usm_u16(swatches, shape, amount):
 def test_usm_rows_carried_between_tiles(swatches, monkeypatch, max_wg, seg_tiles, radius):
     """Consecutive tiles of a vertical segment hand their lower halo rows to the next tile instead of
     recomputing them, and workgroups draw further segments from a ticket counter.  SS_USM_SEG_TILES sets the
-    segment length and SS_USM_MAX_WG limits the workgroups, so that on this small batch (2 images of 4 x 8
-    tiles, 128 x 32 pixels each) every workgroup walks several multi-tile segments."""
+    segment length and SS_USM_MAX_WG limits the workgroups, so that on this small batch (2 images of 4 x 10
+    tiles of 128 x 24 pixels) every workgroup walks several multi-tile segments."""
     M_T, M_R = swatches
     monkeypatch.setenv("SS_USM_MAX_WG", str(max_wg))
     monkeypatch.setenv("SS_USM_SEG_TILES", str(seg_tiles))
