@@ -203,9 +203,6 @@ __device__ __forceinline__ LabFT<V> linear_to_labf(const PxT<V> lin, const Chain
   return f;
 }
 
-__device__ __forceinline__ bool all_lanes(bool p) { return __all(p) != 0; }
-__device__ __forceinline__ bool both(bool p) { return p; }
-__device__ __forceinline__ bool both(v2i p) { return (p.x & p.y) != 0; }
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ v2f vmin(v2f a, v2f b) { return v2f{fminf(a.x, b.x), fminf(a.y, b.y)}; }
 
@@ -214,35 +211,26 @@ template <class V>
 __device__ __forceinline__ V finv_delta_cubic(V f, V d) {
   return d * mad<V>(d, d, (f * (f + d)) * 3.0f);
 }
-// ... and anywhere.  g is the cube with its tangent line at T = 6/29 substituted below T:
-// g(f) = f^3 - e(f), e(f) = min(f - T, 0)^2 (f + 2T).  e is small (< 0.018) and smooth, so its plain
-// difference adds no error that matters, and no select is needed.
-template <class V>
-__device__ __forceinline__ V finv_tangent_gap(V f) {
-  const V m = vmin(f - 24.0f / 116.0f, (V)(0.0f));
-  return (m * m) * (f + 48.0f / 116.0f);
-}
+// ... and anywhere.  g is the cube with its tangent line at T = 6/29 substituted below T, i.e.
+// g(f) = max(f, T)^3 + 3 T^2 min(f - T, 0).  With m = min(f - T, 0) and c = f - m = max(f, T):
+//   g(f + d) - g(f) = dc (3 c c2 + dc^2) + 3 T^2 dm,   dm = m2 - m,  dc = d - dm.
+// On the cubic segment dm = 0 exactly and dc = d exactly; below T the quantities are small.  No select.
 template <class V>
 __device__ __forceinline__ V finv_delta_any(V f, V d) {
-  return finv_delta_cubic(f, d) - (finv_tangent_gap(f + d) - finv_tangent_gap(f));
+  constexpr float T = 24.0f / 116.0f;
+  const V f2 = f + d;
+  const V m = vmin(f - T, (V)(0.0f)), m2 = vmin(f2 - T, (V)(0.0f));
+  const V dm = m2 - m, dc = d - dm;
+  const V c = f - m, c2 = f2 - m2;
+  return mad<V>(dm, 3.0f * T * T, dc * mad<V>(dc, dc, (c * c2) * 3.0f));
 }
 
 // clip(encode(linear + M_inv * (g(f + df) - g(f)))): what _lab_to_rgb returns for the edited pixel
 template <class V>
 __device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy, const V dfz,
                                               const ChainParams& P) {
-  V dx, dy, dz;
-  // wave-uniform choice: almost every wave has all its pixels on the cubic segment
-  const V lowest = vmin(vmin(vmin(f.fx, f.fy), f.fz), vmin(vmin(f.fx + dfx, f.fy + dfy), f.fz + dfz));
-  if (all_lanes(both(lowest > (V)(24.0f / 116.0f)))) {
-    dx = finv_delta_cubic(f.fx, dfx);
-    dy = finv_delta_cubic(f.fy, dfy);
-    dz = finv_delta_cubic(f.fz, dfz);
-  } else {
-    dx = finv_delta_any(f.fx, dfx);
-    dy = finv_delta_any(f.fy, dfy);
-    dz = finv_delta_any(f.fz, dfz);
-  }
+  // (a wave-uniform shortcut for "every pixel on the cubic segment" costs as much to decide as it saves)
+  const V dx = finv_delta_any(f.fx, dfx), dy = finv_delta_any(f.fy, dfy), dz = finv_delta_any(f.fz, dfz);
   PxT<V> o;
   o.r = clamp01(srgb_encode(mad<V>(P.m_inv[0], dx, mad<V>(P.m_inv[1], dy, mad<V>(P.m_inv[2], dz, lin.r)))));
   o.g = clamp01(srgb_encode(mad<V>(P.m_inv[3], dx, mad<V>(P.m_inv[4], dy, mad<V>(P.m_inv[5], dz, lin.g)))));
@@ -634,6 +622,9 @@ __device__ __forceinline__ PxT<V> finish(PxT<V> p, const ChainParams& P) {
 // np.uint16(np.clip(x*65535, 0, 65535)) / np.uint8(np.clip(x*255, 0, 255)): truncation toward zero
 __device__ __forceinline__ uint32_t quant16(float x) { return (uint32_t)clampf(x * 65535.0f, 0.0f, 65535.0f); }
 __device__ __forceinline__ uint32_t quant8(float x) { return (uint32_t)clampf(x * 255.0f, 0.0f, 255.0f); }
+// the same for x known to lie in [0, 1]: the product cannot leave the range, the conversion truncates
+__device__ __forceinline__ uint32_t quant16_unit(float x) { return (uint32_t)(x * 65535.0f); }
+__device__ __forceinline__ uint32_t quant8_unit(float x) { return (uint32_t)(x * 255.0f); }
 
 // lane granularity per output kind: G adjacent pixels per lane make a 12-byte store
 template <int OUT>

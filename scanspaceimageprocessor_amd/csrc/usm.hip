@@ -37,9 +37,12 @@ constexpr int USM_WAVES_PER_SIMD = 2 * USM_NT / 256;  // two workgroups per CU
 #define SS_USM_PREFETCH 13  // phase-1 pixels in flight per thread (13 = the whole tile at r = 6)
 #endif
 
-template <int OUT>
+// UNIT: the values are known to lie in [0, 1] (no clamp needed before the truncating conversion)
+template <int OUT, bool UNIT>
 __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int y, int x, const Px o0, const Px o1) {
   if (y >= H || x >= W) return;
+  auto q16 = [](float v) -> uint32_t { return UNIT ? quant16_unit(v) : quant16(v); };
+  auto q8 = [](float v) -> uint32_t { return UNIT ? quant8_unit(v) : quant8(v); };
   const bool two = x + 1 < W;
   const size_t px = (size_t)y * W + x;
   if constexpr (OUT == SS_OUT_F32_LINEAR || OUT == SS_OUT_F32_SRGB) {
@@ -50,30 +53,30 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
     char* d = reinterpret_cast<char*>(dst_img) + px * 6;
     if (two && ((px * 6) & 3) == 0) {
       U3 q;
-      q.x = quant16(o0.r) | (quant16(o0.g) << 16);
-      q.y = quant16(o0.b) | (quant16(o1.r) << 16);
-      q.z = quant16(o1.g) | (quant16(o1.b) << 16);
+      q.x = q16(o0.r) | (q16(o0.g) << 16);
+      q.y = q16(o0.b) | (q16(o1.r) << 16);
+      q.z = q16(o1.g) | (q16(o1.b) << 16);
       *reinterpret_cast<U3*>(d) = q;
     } else {
       uint16_t* h = reinterpret_cast<uint16_t*>(d);
-      h[0] = (uint16_t)quant16(o0.r);
-      h[1] = (uint16_t)quant16(o0.g);
-      h[2] = (uint16_t)quant16(o0.b);
+      h[0] = (uint16_t)q16(o0.r);
+      h[1] = (uint16_t)q16(o0.g);
+      h[2] = (uint16_t)q16(o0.b);
       if (two) {
-        h[3] = (uint16_t)quant16(o1.r);
-        h[4] = (uint16_t)quant16(o1.g);
-        h[5] = (uint16_t)quant16(o1.b);
+        h[3] = (uint16_t)q16(o1.r);
+        h[4] = (uint16_t)q16(o1.g);
+        h[5] = (uint16_t)q16(o1.b);
       }
     }
   } else {
     uint8_t* d = reinterpret_cast<uint8_t*>(dst_img) + px * 3;
-    d[0] = (uint8_t)quant8(o0.r);
-    d[1] = (uint8_t)quant8(o0.g);
-    d[2] = (uint8_t)quant8(o0.b);
+    d[0] = (uint8_t)q8(o0.r);
+    d[1] = (uint8_t)q8(o0.g);
+    d[2] = (uint8_t)q8(o0.b);
     if (two) {
-      d[3] = (uint8_t)quant8(o1.r);
-      d[4] = (uint8_t)quant8(o1.g);
-      d[5] = (uint8_t)quant8(o1.b);
+      d[3] = (uint8_t)q8(o1.r);
+      d[4] = (uint8_t)q8(o1.g);
+      d[5] = (uint8_t)q8(o1.b);
     }
   }
 }
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #ifdef SS_ABL_NO_STORE
         asm volatile("" ::"v"(o.r.x), "v"(o.r.y), "v"(o.g.x), "v"(o.g.y), "v"(o.b.x), "v"(o.b.y));
 #else
-        usm_store_pair<OUT>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
+        usm_store_pair<OUT, PLAIN>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
 #endif
       };
       if constexpr (R_T != 0) {
