@@ -135,3 +135,36 @@ def test_config2_24mp_windows_and_batch_invariance(swatches, textured_24mp, amou
     if amount == 1.0:
         single = run_chain_dev(img, ccm=fit(M_T, M_R), gains=[mult], usm=(amount, radius, 0.0), final_clip=True, out="u16")[0]
         assert np.array_equal(single, got[0])
+
+
+def test_chart_path_with_adjustments_24mp_sampled_pixels_u16(swatches):
+    """The worker's chart path with exposure and shadows/highlights, 16-bit sRGB output: the Lab edit followed by
+    the encode is where float32 is tightest (near-black channels of saturated colours)."""
+    M_T, M_R = swatches
+    img = inputs.linear_image(555, H24, W24)
+    got = run_chain_dev(img, ccm=fit(M_T, M_R), gains=[1.1, 2.0 ** 0.25], sh=(25.0 / 70, -0.3 * 1.3, 7.0),
+                        final_clip=True, out="u16")[0]
+    ys, xs = _sample(H24, W24, 300_000, 4)
+    c = oc.worker_chart_path(img[ys, xs][None], M_T, M_R, multiplier=1.1, exposure_adj=0.25, shadow_adj=25.0,
+                             highlight_adj=-0.3)
+    want = oc.encode_image(c, ".tiff", 16)[0]
+    diff = np.abs(got[ys, xs].astype(np.int64) - want.astype(np.int64))
+    assert diff.max() <= 1
+
+
+def test_no_chart_path_24mp_windows_u16(textured_24mp):
+    """The worker's no-chart path (exposure, shadows/highlights, sharpen radius 1) at 24 MP, on windows."""
+    img = textured_24mp
+    margin = 12
+    got = run_chain_dev(img, gains=[2.0 ** 0.2], sh=(20.0 / 70, -0.25 * 1.3, 7.0), usm=(45.0, 1.0, 0.0),
+                        final_clip=True, out="u16")[0]
+    worst = 0
+    for (y0, y1, x0, x1) in _windows(H24, W24):
+        ey0, ey1 = max(0, y0 - margin), min(H24, y1 + margin)
+        ex0, ex1 = max(0, x0 - margin), min(W24, x1 + margin)
+        c = oc.worker_nochart_path(img[ey0:ey1, ex0:ex1], exposure_adj=0.2, shadow_adj=20.0, highlight_adj=-0.25,
+                                   sharpen_amount=45.0)
+        want = oc.encode_image(c, ".tiff", 16)[y0 - ey0:y1 - ey0, x0 - ex0:x1 - ex0]
+        diff = np.abs(got[y0:y1, x0:x1].astype(np.int64) - want.astype(np.int64))
+        worst = max(worst, int(diff.max()))
+    assert worst <= 1
