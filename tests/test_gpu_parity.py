@@ -413,3 +413,39 @@ def test_bad_descriptors_are_rejected():
         run_chain_dev(img, usm=(10.0, 9.0, 0.0))  # 55-tap kernel: unsupported
     with pytest.raises(_lib.ScanSpaceError):
         run_chain_dev(img, sh=(1.0, 0.0, 7.0), lab_io=True, final_clip=True)
+
+
+# ---- re-entrancy: one context per worker thread (image_space.py:3483 runs N workers at once) --------
+
+
+def test_worker_threads_with_their_own_contexts_agree_with_serial_runs(swatches):
+    import threading
+
+    M_T, M_R = swatches
+    imgs = [inputs.smooth_image(300 + i, 260, 300 + 16 * i) for i in range(6)]
+
+    def work(i):
+        # through the drop-in Python entry points: each thread gets its own context (own stream, own
+        # workspace, own work-queue counter)
+        out = et.adjust_sharpen(et.adjust_shadows_highlights_combined(imgs[i], 0.3, -0.2), 40.0 + i, 2.0, 0.0)
+        return out
+
+    serial = [work(i) for i in range(len(imgs))]
+    results = [None] * len(imgs)
+    errors = []
+
+    def runner(i):
+        try:
+            for _ in range(3):
+                results[i] = work(i)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=runner, args=(i,)) for i in range(len(imgs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for a, b in zip(serial, results):
+        np.testing.assert_array_equal(a, b)
