@@ -124,12 +124,14 @@ def main():
         img = torch.rand((H, W, 3), generator=g, device=dev, dtype=torch.float32)
         img.pow_(2.2).mul_(0.9 * float(scales[first + i])).clamp_(0.0, 1.0)
         images[i] = img
-        t = torch.nn.functional.adaptive_avg_pool2d(img.permute(2, 0, 1).unsqueeze(0), (THUMB_H, THUMB_W))
-        thumbs[i] = t.squeeze(0).permute(1, 2, 0)
-        del img, t
+        del img
     out = torch.empty((B, H, W, 3), dtype=torch.int16, device=dev)  # uint16 payload
 
     ctx = Context(local_rank)
+    # the 512-pixel thumbnails the exposure statistics read: the loader's area-average downscale, on the device
+    torch.cuda.synchronize(dev)
+    ctx.resize_area(images.data_ptr(), H, W, B, thumbs.data_ptr(), THUMB_H, THUMB_W)
+    ctx.sync()
     # one dedicated stream carries the library's kernels, the collective and the timing events
     stream = torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)

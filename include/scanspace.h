@@ -221,6 +221,21 @@ int ss_exposure_multipliers(ss_ctx* ctx, const float* brightness_dev, int32_t n,
  * Asynchronous. */
 int ss_is_lab_image(ss_ctx* ctx, const float* src_dev, int64_t n_pixels, int32_t* out_dev, float* minmax_dev);
 
+/* ---- preview / thumbnail producers --------------------------------------------------------- */
+
+/* cv2.resize(src, (dst_width, dst_height), interpolation=cv2.INTER_AREA) for a batch of interleaved float32 RGB
+ * images, downscaling only (dst_height <= height, dst_width <= width): the 1 MP RAW preview
+ * (imageLoader.py:94-121), the <= 512 px thumbnails (imageLoader.py:298-302) and the 4 MP edit preview
+ * (image_space.py:2959-2986).  Each destination pixel is the area-weighted mean of the source rectangle it
+ * covers (OpenCV's computeResizeAreaTab weights, float32 accumulation, rows reduced first).
+ * src_dev: [batch][height][width][3], dst_dev: [batch][dst_height][dst_width][3].  Asynchronous. */
+int ss_resize_area(ss_ctx* ctx, const float* src_dev, int32_t height, int32_t width, int32_t batch, float* dst_dev,
+                   int32_t dst_height, int32_t dst_width);
+
+/* The same for one host image: upload, resize, download (synchronous, through the pinned staging ring). */
+int ss_resize_area_host(ss_ctx* ctx, const float* src_host, int32_t height, int32_t width, float* dst_host,
+                        int32_t dst_height, int32_t dst_width);
+
 /* ---- plain device memory helpers for hosts without another HIP binding -------------------- */
 
 int ss_malloc(ss_ctx* ctx, uint64_t bytes, void** out_dev);

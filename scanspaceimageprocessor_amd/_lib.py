@@ -102,6 +102,9 @@ SIGNATURES = {
     "ss_exposure_multipliers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p]),
     "ss_is_lab_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ss_resize_area": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                 C.c_int32]),
+    "ss_resize_area_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "ss_malloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "ss_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -220,6 +223,21 @@ class Context:
     def is_lab_image(self, src_dev, n_pixels, out_dev, minmax_dev=None):
         self.check(self.lib.ss_is_lab_image(self.handle, C.c_void_p(src_dev), int(n_pixels),
                                             C.c_void_p(out_dev), C.c_void_p(minmax_dev or None)))
+
+    def resize_area(self, src_dev, height, width, batch, dst_dev, dst_height, dst_width):
+        """Area-average downscale of [batch][height][width][3] float32 on the device (asynchronous)."""
+        self.check(self.lib.ss_resize_area(self.handle, C.c_void_p(src_dev), int(height), int(width), int(batch),
+                                           C.c_void_p(dst_dev), int(dst_height), int(dst_width)))
+
+    def resize_area_host(self, src, dst_width, dst_height):
+        """``cv2.resize(src, (dst_width, dst_height), interpolation=cv2.INTER_AREA)`` for an (H, W, 3) array."""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        if src.ndim != 3 or src.shape[2] != 3:
+            raise ValueError(f"expected an (H, W, 3) array, got {src.shape}")
+        out = np.empty((int(dst_height), int(dst_width), 3), dtype=np.float32)
+        self.check(self.lib.ss_resize_area_host(self.handle, src.ctypes.data_as(C.c_void_p), src.shape[0], src.shape[1],
+                                                out.ctypes.data_as(C.c_void_p), int(dst_height), int(dst_width)))
+        return out
 
     # -- entry point on host arrays
     def chain_run_host(self, desc, src, neg_auto=False, low=0.05, high=0.995, legacy_numpy=True, lab_auto=False):

@@ -532,6 +532,40 @@ int ss_is_lab_image(ss_ctx* c, const float* src_dev, int64_t n_pixels, int32_t* 
   return SS_OK;
 }
 
+int ss_resize_area(ss_ctx* c, const float* src_dev, int32_t height, int32_t width, int32_t batch, float* dst_dev,
+                   int32_t dst_height, int32_t dst_width) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!src_dev || !dst_dev) return fail(c, SS_ERR_INVALID, "src_dev and dst_dev must not be NULL");
+  if (height < 1 || width < 1 || batch < 1 || batch > 65535)
+    return fail(c, SS_ERR_INVALID, "bad source shape %d x %d x %d", batch, height, width);
+  if (dst_height < 1 || dst_width < 1 || dst_height > height || dst_width > width || dst_height > 65535)
+    return fail(c, SS_ERR_INVALID, "area resize only shrinks: %d x %d -> %d x %d", height, width, dst_height, dst_width);
+  hipError_t e = launch_resize_area(src_dev, height, width, batch, dst_dev, dst_height, dst_width, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "resize kernel failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_resize_area_host(ss_ctx* c, const float* src_host, int32_t height, int32_t width, float* dst_host,
+                        int32_t dst_height, int32_t dst_width) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!src_host || !dst_host) return fail(c, SS_ERR_INVALID, "src_host and dst_host must not be NULL");
+  if (height < 1 || width < 1 || dst_height < 1 || dst_width < 1)
+    return fail(c, SS_ERR_INVALID, "bad shape");
+  const size_t in_bytes = (size_t)height * width * 3 * sizeof(float);
+  const size_t out_bytes = (size_t)dst_height * dst_width * 3 * sizeof(float);
+  rc = grow(c, &c->host_src, &c->host_src_bytes, in_bytes);
+  if (rc) return rc;
+  rc = grow(c, &c->host_dst, &c->host_dst_bytes, out_bytes);
+  if (rc) return rc;
+  rc = copy_h2d(c, c->host_src, src_host, in_bytes);
+  if (rc) return rc;
+  rc = ss_resize_area(c, (const float*)c->host_src, height, width, 1, (float*)c->host_dst, dst_height, dst_width);
+  if (rc) return rc;
+  return copy_d2h(c, dst_host, c->host_dst, out_bytes);
+}
+
 int ss_malloc(ss_ctx* c, uint64_t bytes, void** out_dev) {
   int rc = check_ctx(c);
   if (rc) return rc;

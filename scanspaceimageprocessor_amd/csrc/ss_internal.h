@@ -40,6 +40,9 @@ hipError_t launch_exposure_multipliers(const float* brightness, int n, int ref_i
                                        float* mult, hipStream_t st);
 
 constexpr int kLabDetectBlocks = 1024;
+// area-average downscale (resize.hip); dh <= sh, dw <= sw
+hipError_t launch_resize_area(const float* src, int sh, int sw, int batch, float* dst, int dh, int dw, hipStream_t st);
+
 hipError_t launch_is_lab(const float* src, int64_t n_px, float* partials /*[kLabDetectBlocks][3]*/, int32_t* out,
                          float* minmax, hipStream_t st);
 

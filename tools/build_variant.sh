@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../scanspaceimageprocessor_amd/csrc"
 name=$1; shift
 mkdir -p ../variants build/$name
-for f in chain usm stats api; do
+for f in chain usm stats resize api; do
   if [ "$f" = usm ] || [ ! -f build/$f.o ]; then
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -fno-slp-vectorize "$@" -c $f.hip -o build/$name/$f.o &
   else
