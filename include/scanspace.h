@@ -236,6 +236,18 @@ int ss_resize_area(ss_ctx* ctx, const float* src_dev, int32_t height, int32_t wi
 int ss_resize_area_host(ss_ctx* ctx, const float* src_host, int32_t height, int32_t width, float* dst_host,
                         int32_t dst_height, int32_t dst_width);
 
+/* ---- shadow / highlight region masking ------------------------------------------------------ */
+
+/* _apply_masking (imageProcessorWorker.py:979-1030), the step between the chain's last clip and the encode when
+ * `export_masked` is set: luminance 0.2126 R + 0.7152 G + 0.0722 B (float64, as on the reference's float64 image);
+ * candidate pixels are those with luminance <= shadow_limit or >= highlight_limit; 8-connected components of
+ * candidates (cv2.connectedComponentsWithStats(mask, connectivity=8)) with an area of at least min_area pixels
+ * (the reference hard-wires 200) are set to 0 in place.  img_dev: [batch][height][width][3] float32.
+ * masked_count_dev: optional device uint64[batch], the number of pixels zeroed per image (the reference logs it).
+ * The set of zeroed pixels is exactly the reference's for the same input values.  Asynchronous. */
+int ss_mask_regions(ss_ctx* ctx, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
+                    double highlight_limit, int32_t min_area, uint64_t* masked_count_dev);
+
 /* ---- plain device memory helpers for hosts without another HIP binding -------------------- */
 
 int ss_malloc(ss_ctx* ctx, uint64_t bytes, void** out_dev);

@@ -102,6 +102,8 @@ SIGNATURES = {
     "ss_exposure_multipliers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p]),
     "ss_is_lab_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ss_mask_regions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                  C.c_int32, C.c_void_p]),
     "ss_resize_area": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32]),
     "ss_resize_area_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
@@ -223,6 +225,13 @@ class Context:
     def is_lab_image(self, src_dev, n_pixels, out_dev, minmax_dev=None):
         self.check(self.lib.ss_is_lab_image(self.handle, C.c_void_p(src_dev), int(n_pixels),
                                             C.c_void_p(out_dev), C.c_void_p(minmax_dev or None)))
+
+    def mask_regions(self, img_dev, height, width, batch, shadow_limit, highlight_limit, min_area=200, count_dev=None):
+        """Zero, in place, the 8-connected regions of at least ``min_area`` pixels whose luminance is <= shadow_limit
+        or >= highlight_limit (asynchronous).  ``count_dev``: optional device uint64[batch] of zeroed pixels."""
+        self.check(self.lib.ss_mask_regions(self.handle, C.c_void_p(img_dev), int(height), int(width), int(batch),
+                                            float(shadow_limit), float(highlight_limit), int(min_area),
+                                            C.c_void_p(count_dev or None)))
 
     def resize_area(self, src_dev, height, width, batch, dst_dev, dst_height, dst_width):
         """Area-average downscale of [batch][height][width][3] float32 on the device (asynchronous)."""

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libscanspace_hip.so")
-SOURCES = ["chain.hip", "usm.hip", "stats.hip", "resize.hip", "api.hip"]
+SOURCES = ["chain.hip", "usm.hip", "stats.hip", "resize.hip", "mask.hip", "api.hip"]
 HEADERS = ["ss_device.h", "ss_internal.h", os.path.join("..", "..", "include", "scanspace.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 # Per-file flags.  usm.hip packs its pair arithmetic explicitly; the SLP vectoriser's own pairs in phase 1

@@ -35,6 +35,8 @@ struct ss_ctx {
   uint32_t* usm_ticket = nullptr;  // segment counter of the unsharp-mask kernel's work queue
   void* ws_stage = nullptr;        // float32 images between the two passes of a staged chain
   size_t ws_stage_bytes = 0;
+  void* ws_mask = nullptr;         // labels and areas of the region masking
+  size_t ws_mask_bytes = 0;
   // host path
   void* pinned[2] = {nullptr, nullptr};
   hipEvent_t pinned_free[2] = {nullptr, nullptr};
@@ -383,6 +385,7 @@ void ss_ctx_destroy(ss_ctx* c) {
   if (c->ws_small) hipFree(c->ws_small);
   if (c->usm_ticket) hipFree(c->usm_ticket);
   if (c->ws_stage) hipFree(c->ws_stage);
+  if (c->ws_mask) hipFree(c->ws_mask);
   if (c->host_src) hipFree(c->host_src);
   if (c->host_dst) hipFree(c->host_dst);
   if (c->host_neg) hipFree(c->host_neg);
@@ -529,6 +532,24 @@ int ss_is_lab_image(ss_ctx* c, const float* src_dev, int64_t n_pixels, int32_t* 
   if (rc) return rc;
   hipError_t e = launch_is_lab(src_dev, n_pixels, (float*)c->ws_small, out_dev, minmax_dev, c->stream);
   if (e != hipSuccess) return fail(c, SS_ERR_HIP, "lab-detect kernels failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_mask_regions(ss_ctx* c, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
+                    double highlight_limit, int32_t min_area, uint64_t* masked_count_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!img_dev) return fail(c, SS_ERR_INVALID, "img_dev must not be NULL");
+  if (height < 1 || width < 1 || batch < 1 || batch > 65535 || height > 65535 ||
+      (int64_t)height * width > INT32_MAX)
+    return fail(c, SS_ERR_INVALID, "bad image shape %d x %d x %d", batch, height, width);
+  if (!(shadow_limit == shadow_limit) || !(highlight_limit == highlight_limit))
+    return fail(c, SS_ERR_INVALID, "limits must not be NaN");
+  rc = grow(c, &c->ws_mask, &c->ws_mask_bytes, mask_workspace_bytes(batch, (int64_t)height * width));
+  if (rc) return rc;
+  hipError_t e = launch_mask_regions(img_dev, height, width, batch, shadow_limit, highlight_limit, min_area, c->ws_mask,
+                                     reinterpret_cast<unsigned long long*>(masked_count_dev), c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "masking kernels failed to launch: %s", hipGetErrorString(e));
   return SS_OK;
 }
 

@@ -40,6 +40,13 @@ hipError_t launch_exposure_multipliers(const float* brightness, int n, int ref_i
                                        float* mult, hipStream_t st);
 
 constexpr int kLabDetectBlocks = 1024;
+// ---- mask.hip ----------------------------------------------------------------------------------
+// _apply_masking: candidates by luminance, 8-connected components, components >= min_area zeroed in place.
+// workspace: mask_workspace_bytes(batch, n_px) bytes of device memory; count_dev: optional [batch] counters.
+size_t mask_workspace_bytes(int batch, int64_t n_px);
+hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shadow_limit, double highlight_limit,
+                               int min_area, void* workspace, unsigned long long* count_dev, hipStream_t st);
+
 // area-average downscale (resize.hip); dh <= sh, dw <= sw
 hipError_t launch_resize_area(const float* src, int sh, int sw, int batch, float* dst, int dh, int dw, hipStream_t st);
 

@@ -1,0 +1,122 @@
+"""Shadow / highlight region masking (the worker's _apply_masking) through the C ABI, against
+oracle/masking.py.  The zeroed pixel set and its size must match exactly."""
+
+import numpy as np
+import pytest
+
+from gpu_util import DeviceBuffer
+from oracle import inputs
+from oracle import masking as om
+from scanspaceimageprocessor_amd import default_context
+
+pytestmark = pytest.mark.gpu
+
+
+def run_mask(imgs, shadow=0.05, highlight=0.98, min_area=200):
+    ctx = default_context()
+    imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+    if imgs.ndim == 3:
+        imgs = imgs[None]
+    b, h, w, _ = imgs.shape
+    buf = DeviceBuffer.from_array(ctx, imgs)
+    cnt = DeviceBuffer(ctx, 8 * b)
+    try:
+        ctx.mask_regions(buf.ptr, h, w, b, shadow, highlight, min_area, cnt.ptr)
+        ctx.sync()
+        return buf.to_array(imgs.shape, np.float32), cnt.to_array((b,), np.uint64)
+    finally:
+        buf.free(); cnt.free()
+
+
+def check(imgs, **kw):
+    imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+    if imgs.ndim == 3:
+        imgs = imgs[None]
+    got, counts = run_mask(imgs, **kw)
+    for i in range(imgs.shape[0]):
+        want, n = om.apply_masking(imgs[i], kw.get("shadow", 0.05), kw.get("highlight", 0.98), kw.get("min_area", 200))
+        np.testing.assert_array_equal(got[i], want.astype(np.float32))
+        assert int(counts[i]) == n
+
+
+def from_mask(mask, seed=0):
+    """An image whose candidate mask is exactly `mask` (dark where set, mid-grey noise elsewhere)."""
+    rng = np.random.default_rng(seed)
+    img = (0.2 + 0.6 * rng.random(mask.shape + (3,))).astype(np.float32)
+    img[mask] = 0.01
+    return img
+
+
+def test_blobs_and_specks():
+    rng = np.random.default_rng(1)
+    h, w = 300, 500
+    mask = np.zeros((h, w), bool)
+    for _ in range(40):
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(2, 25)
+        yy, xx = np.ogrid[:h, :w]
+        mask |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+    mask |= rng.random((h, w)) < 0.02  # specks, most of them below the area threshold
+    check(from_mask(mask))
+
+
+@pytest.mark.parametrize("density", [0.3, 0.4, 0.5, 0.6])
+def test_random_masks_around_the_percolation_threshold(density):
+    rng = np.random.default_rng(int(density * 100))
+    check(from_mask(rng.random((257, 389)) < density, seed=3), min_area=50)
+
+
+def test_long_thin_structures():
+    h, w = 200, 1300  # wider than one scan chunk of 1024 pixels
+    mask = np.zeros((h, w), bool)
+    mask[::4, :] = True            # long rows ...
+    mask[:, 5] = True              # ... joined by one column into a comb
+    mask[1::4, 700:] = False
+    spiral = np.zeros((h, w), bool)
+    for k in range(0, 90, 4):      # nested rectangles linked at a corner each: a long winding component
+        spiral[k, k:w - k] = True
+        spiral[h - 1 - k, k:w - k] = True
+        spiral[k:h - k, k] = True
+        spiral[k:h - k, w - 1 - k] = True
+    check(from_mask(mask))
+    check(from_mask(spiral))
+    diag = np.zeros((300, 300), bool)
+    idx = np.arange(300)
+    diag[idx, idx] = True          # 8-connectivity only
+    diag[idx[:-1], idx[:-1] + 1] |= (idx[:-1] % 7 == 0)
+    check(from_mask(diag))
+    anti = diag[:, ::-1].copy()    # contacts arrive from the upper right
+    check(from_mask(anti))
+
+
+def test_area_threshold_and_limits_are_inclusive():
+    mask = np.zeros((60, 60), bool)
+    mask[2:12, 3:23] = True    # exactly 200
+    mask[30:40, 3:22] = True   # 190
+    check(from_mask(mask))
+    img = np.full((20, 20, 3), 0.5, np.float32)
+    img[:, :10] = np.float32(0.05)   # float32(0.05) > 0.05 in float64: not a candidate by the shadow limit
+    img[:, 10:] = np.float32(0.98)   # float32(0.98) < 0.98: not a candidate either
+    check(img, min_area=1)
+    img[:, :10] = np.float32(0.049999997)
+    check(img, min_area=1)
+    check(inputs.linear_image(5, 120, 160), shadow=0.02, highlight=0.5, min_area=3)
+
+
+def test_everything_and_nothing_masked_and_a_batch():
+    check(np.zeros((50, 70, 3), np.float32))
+    check(np.full((50, 70, 3), 0.5, np.float32))
+    imgs = np.stack([inputs.linear_image(20 + i, 180, 240) for i in range(3)])
+    check(imgs, shadow=0.03, highlight=0.6, min_area=20)
+
+
+def test_24mp_dark_background_with_an_object():
+    h, w = 4000, 6000
+    rng = np.random.default_rng(7)
+    img = (0.01 * rng.random((h, w, 3))).astype(np.float32)            # dark backdrop: one huge component
+    yy, xx = np.ogrid[:h, :w]
+    obj = ((yy - 2000) / 1500.0) ** 2 + ((xx - 3000) / 2200.0) ** 2 <= 1.0
+    img[obj] = (0.08 + 0.8 * rng.random((int(obj.sum()), 3))).astype(np.float32)
+    holes = obj & (rng.random((h, w)) < 0.001)                          # dark specks inside the object: too small
+    img[holes] = 0.0
+    img[1900:2100, 2900:3100] = 0.995                                   # a blown highlight patch
+    check(img)

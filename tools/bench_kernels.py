@@ -65,7 +65,7 @@ def main():
 
     todo = args.configs.split(",")
     H, W, B = 4000, 6000, args.batch
-    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "5", "5b", "5c", "t")):
+    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "5", "5b", "5c", "t", "m")):
         img = images(H, W, B)
         out = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
     if "1" in todo:
@@ -101,6 +101,22 @@ def main():
             small = torch.empty((B, dh, dw, 3), dtype=torch.float32, device=dev)
             report(f"t  area resize -> {name}", H, W, B, 12 + 12 * dw * dh / (H * W),
                    *timeit(lambda: ctx.resize_area(img.data_ptr(), H, W, B, small.data_ptr(), dh, dw)))
+    if "m" in todo:  # region masking: an object on a dark backdrop, and white noise (many tiny components)
+        yy = torch.arange(H, device=dev, dtype=torch.float32)[:, None]
+        xx = torch.arange(W, device=dev, dtype=torch.float32)[None, :]
+        inside = (((yy - H / 2) / (0.38 * H)) ** 2 + ((xx - W / 2) / (0.36 * W)) ** 2 <= 1.0)[None, :, :, None]
+        scene = torch.where(inside, 0.08 + 0.8 * img, 0.01 * img).contiguous()
+        work = torch.empty_like(scene)
+        cnt = torch.zeros(B, dtype=torch.int64, device=dev)
+        for name, data, lims in (("m  mask: object on dark backdrop", scene, (0.05, 0.98)), ("m  mask: noise", img, (0.05, 0.6))):
+            work.copy_(data)
+            torch.cuda.synchronize()
+            # in place and repeatable: zeroed pixels stay candidates, so every repetition labels the same mask
+            report(name, H, W, B, 12, *timeit(lambda: ctx.mask_regions(work.data_ptr(), H, W, B, lims[0], lims[1], 200,
+                                                                        cnt.data_ptr())))
+            ctx.sync()
+            print(f"     masked pixels per image: {cnt.tolist()[:3]} ...")
+        del scene, work
     if "3" in todo:
         neg = images(H, W, B, negative=True)
         params = torch.empty((B, _lib.SS_NEG_PARAM_STRIDE), dtype=torch.float32, device=dev)
