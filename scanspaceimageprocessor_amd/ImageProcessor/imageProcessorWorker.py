@@ -12,7 +12,7 @@ failing image is reported as ``'error'`` and the loop continues.
 Different by design: ``run`` keeps each image on the GPU between its steps (one upload, one fused
 kernel pass per output, downloads of the encoded result and of the 8-bit preview only).  RAW
 decoding (rawpy) and file encoding (imageio / tifffile) stay on the host and are looked up at
-call time; metadata embedding, path schemas and luminance masking are outside this package.
+call time; metadata embedding and path schemas are outside this package.
 """
 
 from __future__ import annotations
@@ -256,6 +256,21 @@ class ImageCorrectionWorker:
                                     editingTools.NUMPY_LEGACY_PERCENTILE, neg)
                 kw.update(neg=True, neg_params_dev=neg)
             encoded = np.empty(img.shape, dtype=_lib.OUT_DTYPES[kind])
+            if getattr(self, "export_masked", False):
+                # reference order (imageProcessorWorker.py:902-912): chain -> _apply_masking -> encode.  The chain
+                # leaves the clipped linear image in `dst`, the masking zeroes regions in place, and the encode
+                # (a chain with no stage) writes into `src`, whose contents are no longer needed.
+                ctx.chain_run(make_desc(h, w, 1, out="f32", **kw), src, dst)
+                self._apply_masking_device(ctx, dst, h, w)
+                ctx.chain_run(make_desc(h, w, 1, out=kind), dst, src)
+                ctx.download(encoded, src)
+                if encoded.dtype == np.uint8:
+                    preview = encoded
+                else:
+                    preview = np.empty(img.shape, dtype=np.uint8)
+                    ctx.chain_run(make_desc(h, w, 1, out="u8_linear"), dst, src)
+                    ctx.download(preview, src)
+                return encoded, preview
             ctx.chain_run(make_desc(h, w, 1, out=kind, **kw), src, dst)
             ctx.download(encoded, dst)
             if encoded.dtype == np.uint8:
@@ -270,6 +285,45 @@ class ImageCorrectionWorker:
             ctx.free(dst)
             if neg:
                 ctx.free(neg)
+
+    # ------------------------------------------------------------------ masking
+
+    MASK_MIN_AREA = 200  # imageProcessorWorker.py:1005
+
+    def _apply_masking_device(self, ctx, img_dev, h, w):
+        """``_apply_masking`` (imageProcessorWorker.py:979-1030) on an image resident on the GPU, in place."""
+        shadow_limit = getattr(self, "shadow_limit", 0.05)
+        highlight_limit = getattr(self, "highlight_limit", 0.98)
+        count_dev = ctx.malloc(8)
+        try:
+            ctx.mask_regions(img_dev, h, w, 1, shadow_limit, highlight_limit, self.MASK_MIN_AREA, count_dev)
+            count = np.zeros(1, dtype=np.uint64)
+            ctx.download(count, count_dev)
+        finally:
+            ctx.free(count_dev)
+        self.signals.log.emit(
+            f"[Export Masked] Masked {int(count[0])} pixels (min area={self.MASK_MIN_AREA}) "
+            f"with limits shadow<={shadow_limit:.2f}, highlight>={highlight_limit:.2f}"
+        )
+
+    def _apply_masking(self, corrected: np.ndarray) -> np.ndarray:
+        """Host-array form with the reference's signature: zeroes the regions in ``corrected`` (float32 images are
+        modified in place like the reference's array; other dtypes come back as a float32 copy) and returns it."""
+        ctx = default_context()
+        arr = np.ascontiguousarray(corrected, dtype=np.float32)
+        h, w, _ = arr.shape
+        buf = ctx.malloc(arr.nbytes)
+        try:
+            ctx.upload(buf, arr)
+            self._apply_masking_device(ctx, buf, h, w)
+            ctx.download(arr, buf)
+        finally:
+            ctx.free(buf)
+        if arr is not corrected and isinstance(corrected, np.ndarray) and corrected.dtype == np.float32 \
+                and corrected.flags.writeable:
+            corrected[...] = arr
+            return corrected
+        return arr
 
     # ------------------------------------------------------------------ host I/O hooks
 
@@ -311,7 +365,7 @@ class ImageCorrectionWorker:
     # ------------------------------------------------------------------ main loop
 
     def run(self):
-        """Reference imageProcessorWorker.py:815-977 without metadata embedding and masking."""
+        """Reference imageProcessorWorker.py:815-977 without metadata embedding."""
         ext = self.output_format
         for img_path in self.images:
             t0 = time.time()

@@ -1,0 +1,89 @@
+"""The worker mirror end to end on the GPU: ``process_array`` / ``run`` against the oracle's restatement of
+ImageCorrectionWorker.run steps 3-7 (imageProcessorWorker.py:839-923), masking included."""
+
+import numpy as np
+import pytest
+
+from oracle import chain as oc
+from oracle import inputs
+from oracle import masking as om
+from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as ipw
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(seed, h, w):
+    """Bright object with a dark surround and a blown patch: gives the masking something to do."""
+    rng = np.random.default_rng(seed)
+    img = (0.004 * rng.random((h, w, 3))).astype(np.float32)
+    yy, xx = np.ogrid[:h, :w]
+    obj = ((yy - h / 2) / (0.35 * h)) ** 2 + ((xx - w / 2) / (0.3 * w)) ** 2 <= 1.0
+    img[obj] = (0.1 + 0.6 * rng.random((int(obj.sum()), 3))).astype(np.float32)
+    img[h // 2 - 8:h // 2 + 8, w // 2 - 10:w // 2 + 10] = 2.0   # clips to 1 after the correction
+    img[5:8, 5:8] = 0.5                                          # small bright island in the dark surround
+    return img
+
+
+@pytest.mark.parametrize("fmt,depth", [(".tiff", 16), (".jpg", 8), (".exr", 8)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_chart_mode_process_array(fmt, depth, masked):
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    logs = []
+    sig = ipw.WorkerSignals()
+    sig.log.connect(logs.append)
+    w = ipw.ImageCorrectionWorker(["a.nef"], M_T, "/tmp", sig, output_format=fmt, tiff_bitdepth=depth,
+                                  export_masked=masked, exposure_adj=0.2, shadow_adj=10.0)
+    w.image_metadata_map = {"a.nef": {"average_exposure": "1.1"}}
+    w.shadow_limit, w.highlight_limit = 0.06, 0.96
+    img = scene(3, 150, 210)
+    encoded, preview = w.process_array(img, "a.nef")
+
+    c = oc.worker_chart_path(img, M_T, M_R, multiplier=1.1, exposure_adj=0.2, shadow_adj=10.0)
+    if masked:
+        c, n = om.apply_masking(c, 0.06, 0.96, 200)
+        assert n > 200
+        assert any(f"Masked {n} pixels (min area=200) with limits shadow<=0.06, highlight>=0.96" in m for m in logs)
+    want = oc.encode_image(c, fmt, depth)
+    if fmt == ".exr":
+        assert encoded.dtype == np.float32 and np.max(np.abs(encoded - want)) <= 1e-5
+    else:
+        assert encoded.dtype == want.dtype
+        assert np.max(np.abs(encoded.astype(np.int64) - want.astype(np.int64))) <= 1
+    want_preview = want if want.dtype == np.uint8 else np.uint8(np.clip(c * 255.0, 0, 255))
+    assert np.max(np.abs(preview.astype(np.int64) - want_preview.astype(np.int64))) <= 1
+    if masked:  # masked pixels are exactly zero, in the output and in the preview
+        m = (c == 0).all(axis=2)
+        assert (encoded[m] == 0).all() and (preview[m] == 0).all()
+
+
+def test_run_in_no_chart_negative_mode_writes_and_signals(tmp_path):
+    M_T, M_R = inputs.synthetic_swatches()
+    neg = inputs.negative_image(9, 140, 200)
+    written, previews, states = {}, [], []
+    sig = ipw.WorkerSignals()
+    sig.preview.connect(lambda d: previews.append(d))
+    sig.status.connect(lambda *a: states.append(a[1] if len(a) > 1 else a[0]))
+    w = ipw.ImageCorrectionWorker(["n1.nef", "n2.nef"], M_T, str(tmp_path), sig, output_format=".tiff", tiff_bitdepth=16,
+                                  use_chart=False, negative_mode=True, sharpen_amount=35.0, highlight_adj=-0.2)
+    w.raw_loader = lambda path: neg if path == "n1.nef" else neg[::-1].copy()
+    w.image_writer = lambda out_path, arr, ext: written.__setitem__(out_path, arr.copy())
+    w.run()
+    assert states == ["started", "finished", "started", "finished"]
+    assert len(written) == 2 and len(previews) == 2
+    for path, src in (("n1", neg), ("n2", neg[::-1])):
+        got = written[str(tmp_path / (path + ".tiff"))]
+        c = oc.worker_nochart_path(src, negative_mode=True, highlight_adj=-0.2, sharpen_amount=35.0)
+        want = oc.encode_image(c, ".tiff", 16)
+        assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int64))) <= 1
+
+
+def test_host_array_masking_entry_point():
+    M_T, _ = inputs.synthetic_swatches()
+    w = ipw.ImageCorrectionWorker([], M_T, "/tmp", None)
+    img = scene(4, 120, 160)
+    img = np.clip(img, 0, 1)
+    want, n = om.apply_masking(img)
+    out = w._apply_masking(img)
+    assert out is img  # float32 arrays are modified in place, as the reference does with its array
+    np.testing.assert_array_equal(out, want)
