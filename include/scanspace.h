@@ -131,6 +131,9 @@ int ss_ctx_create(int device, ss_ctx** out_ctx);
 void ss_ctx_destroy(ss_ctx* ctx);
 /* Launch on a caller-owned hipStream_t instead of the context's own (NULL restores the own stream). */
 int ss_ctx_set_stream(ss_ctx* ctx, void* hip_stream);
+/* The hipStream_t the context currently launches on (its own or the caller's), so that a host can order other
+ * work - a collective, a copy - on the same stream; NULL for a NULL context. */
+void* ss_ctx_get_stream(ss_ctx* ctx);
 /* Block until everything queued on the context's stream has finished. */
 int ss_ctx_sync(ss_ctx* ctx);
 /* Text of the last error recorded on this context ("" if none); ctx == NULL -> last ss_ctx_create failure. */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ss_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ss_ctx_destroy": (None, [C.c_void_p]),
     "ss_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_ctx_get_stream": (C.c_void_p, [C.c_void_p]),
     "ss_ctx_sync": (C.c_int, [C.c_void_p]),
     "ss_last_error": (C.c_char_p, [C.c_void_p]),
     "ss_version": (C.c_char_p, []),
@@ -174,6 +175,11 @@ class Context:
     # -- streams / sync / timing
     def set_stream(self, hip_stream):
         self.check(self.lib.ss_ctx_set_stream(self.handle, C.c_void_p(hip_stream or None)))
+
+    @property
+    def stream(self):
+        """The raw hipStream_t (integer address) this context launches on."""
+        return int(self.lib.ss_ctx_get_stream(self.handle) or 0)
 
     def sync(self):
         self.check(self.lib.ss_ctx_sync(self.handle))

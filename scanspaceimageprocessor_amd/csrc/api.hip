@@ -406,6 +406,8 @@ int ss_ctx_set_stream(ss_ctx* c, void* hip_stream) {
   return SS_OK;
 }
 
+void* ss_ctx_get_stream(ss_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 int ss_ctx_sync(ss_ctx* c) {
   int rc = check_ctx(c);
   if (rc) return rc;

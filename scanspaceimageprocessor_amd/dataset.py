@@ -77,7 +77,15 @@ class ExposureNormaliser:
     def run(self, thumbs_ptr: int, thumb_h: int, thumb_w: int):
         self.ctx.exposure_stats(thumbs_ptr, thumb_h, thumb_w, self.count, self.shadow_limit, self.highlight_limit,
                                 None, self.brightness.data_ptr())
-        self.brightness_all = gather_brightness(self.brightness, self.n_images, self.group)
+        if self.world > 1:
+            # the collective must follow the statistics kernel and precede the multiplier kernel: issue it on
+            # the context's stream, whatever torch's current stream is
+            import torch
+
+            with torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream, device=self.brightness.device)):
+                self.brightness_all = gather_brightness(self.brightness, self.n_images, self.group)
+        else:
+            self.brightness_all = self.brightness
         self.ctx.exposure_multipliers(self.brightness_all.data_ptr(), self.n_images, self.chart_index,
                                       self.first, self.count, self.gains.data_ptr())
         return self.gains
