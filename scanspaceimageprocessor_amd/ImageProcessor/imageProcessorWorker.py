@@ -342,21 +342,11 @@ class ImageCorrectionWorker:
         if self.image_writer is not None:
             self.image_writer(out_path, encoded, ext)
             return
-        if ext in ('.jpg', '.jpeg'):
-            import imageio
-
-            imageio.imwrite(out_path, encoded, quality=self.jpeg_quality)
-        elif ext == '.png':
-            import imageio
-
-            imageio.imwrite(out_path, encoded)
-        elif ext == '.tiff':
-            from tifffile import tifffile
-
-            with tifffile.TiffWriter(out_path) as tw:
-                tw.write(encoded)
-        else:
+        if ext == '.exr':
             raise NotImplementedError("EXR export goes through OpenImageIO in the reference; supply image_writer")
+        from .imageWriters import write_image
+
+        write_image(out_path, encoded, ext, self.jpeg_quality)
 
     def construct_export_path(self, img_path: str) -> str:
         base = os.path.splitext(os.path.basename(img_path))[0]

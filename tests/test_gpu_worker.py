@@ -87,3 +87,30 @@ def test_host_array_masking_entry_point():
     out = w._apply_masking(img)
     assert out is img  # float32 arrays are modified in place, as the reference does with its array
     np.testing.assert_array_equal(out, want)
+
+
+def test_run_writes_files_with_the_built_in_containers(tmp_path):
+    from scanspaceimageprocessor_amd.ImageProcessor import imageWriters as iw
+
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    img = inputs.linear_image(12, 90, 130)
+    for fmt, depth in ((".tiff", 16), (".tiff", 8), (".png", 8)):
+        out_dir = tmp_path / f"{fmt[1:]}{depth}"
+        out_dir.mkdir()
+        w = ipw.ImageCorrectionWorker(["shot.nef"], M_T, str(out_dir), None, output_format=fmt, tiff_bitdepth=depth)
+        w.raw_loader = lambda path: img
+        states = []
+        w.signals.status.connect(lambda *a: states.append(a[1]))
+        w.run()
+        assert states == ["started", "finished"]
+        want = oc.encode_image(oc.worker_chart_path(img, M_T, M_R), fmt, depth)
+        path = str(out_dir / ("shot" + fmt))
+        if fmt == ".tiff":
+            got = iw.read_tiff(path)
+        else:
+            Image = pytest.importorskip("PIL.Image")
+            with Image.open(path) as im:
+                got = np.asarray(im)
+        assert got.dtype == want.dtype
+        assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int64))) <= 1

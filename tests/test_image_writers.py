@@ -1,0 +1,66 @@
+"""File containers written without the reference's I/O libraries, and the calibration file format."""
+
+import numpy as np
+import pytest
+
+from scanspaceimageprocessor_amd.ImageProcessor import imageWriters as iw
+
+
+@pytest.mark.parametrize("dtype,shape", [(np.uint8, (37, 53, 3)), (np.uint16, (37, 53, 3)), (np.uint16, (5, 7)), (np.uint8, (1, 1, 3))])
+def test_tiff_round_trip_and_pillow_agrees(tmp_path, dtype, shape):
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, np.iinfo(dtype).max + 1, size=shape).astype(dtype)
+    path = str(tmp_path / "a.tiff")
+    iw.write_tiff(path, arr)
+    np.testing.assert_array_equal(iw.read_tiff(path), arr)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    with Image.open(path) as im:  # an independent reader accepts the container
+        assert im.size == (shape[1], shape[0])
+        if dtype == np.uint8 and len(shape) == 3:
+            np.testing.assert_array_equal(np.asarray(im), arr)
+        if dtype == np.uint16 and len(shape) == 2:
+            np.testing.assert_array_equal(np.asarray(im), arr)
+
+
+def test_png_is_read_back_by_pillow(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    for shape in [(40, 61, 3), (9, 4)]:
+        arr = rng.integers(0, 256, size=shape).astype(np.uint8)
+        path = str(tmp_path / "a.png")
+        iw.write_png(path, arr)
+        with Image.open(path) as im:
+            np.testing.assert_array_equal(np.asarray(im), arr)
+
+
+def test_write_image_dispatch_and_rejections(tmp_path):
+    arr = np.zeros((4, 5, 3), np.uint8)
+    iw.write_image(str(tmp_path / "x.tiff"), arr, ".tiff")
+    iw.write_image(str(tmp_path / "x.png"), arr, ".png")
+    with pytest.raises(NotImplementedError):
+        iw.write_image(str(tmp_path / "x.exr"), arr.astype(np.float32), ".exr")
+    with pytest.raises(ValueError):
+        iw.write_tiff(str(tmp_path / "y.tiff"), arr.astype(np.float32))
+    with pytest.raises(ValueError):
+        iw.write_png(str(tmp_path / "y.png"), arr.astype(np.uint16))
+
+
+def test_calibration_files(tmp_path):
+    table = np.random.default_rng(2).random((24, 3)).astype(np.float32)
+    path = str(tmp_path / "chart.npy")
+    iw.save_calibration(path, table)
+    back = iw.load_calibration(path)
+    assert back.dtype == np.float32
+    np.testing.assert_array_equal(back, table)
+    np.testing.assert_array_equal(np.load(path), table)  # a plain np.save file, as the reference reads it
+    with pytest.raises(ValueError):
+        iw.save_calibration(path, table[:, :2])
+    np.save(str(tmp_path / "bad.npy"), np.zeros((3, 4)))
+    with pytest.raises(ValueError):
+        iw.load_calibration(str(tmp_path / "bad.npy"))
+    np.save(str(tmp_path / "obj.npy"), np.array([{"a": 1}], dtype=object), allow_pickle=True)
+    with pytest.raises(ValueError):
+        iw.load_calibration(str(tmp_path / "obj.npy"))
