@@ -106,10 +106,102 @@ __global__ __launch_bounds__(64 * G) void resize_area_kernel(const float* __rest
   if (live) reinterpret_cast<F3*>(dst)[((size_t)blockIdx.z * dh + dy) * dw + dx] = sum;
 }
 
+// Coalesced variant for moderate horizontal reductions.  A workgroup makes kTileDx adjacent destination pixels of
+// one destination row.  Its threads sweep the covered source rows with lane-contiguous 4-byte loads (every
+// source float is read once, by the thread that owns its column position), folding the rows with their
+// vertical weights into per-thread registers; the folded strip goes to LDS and the first 3 * kTileDx threads
+// reduce it horizontally.  Columns are reduced after rows here and before rows in OpenCV: the same sums in
+// another order (a float32 rounding difference, nothing else).
+constexpr int kTileThreads = 256;
+constexpr int kTileMaxScale = 16;                                       // with 64 destination pixels per workgroup
+constexpr int kTileFloats = (64 * kTileMaxScale + 2) * 3;               // strips up to 1026 source pixels: 3078 floats
+constexpr int kTileVecs = (kTileFloats + 4 * kTileThreads - 1) / (4 * kTileThreads);  // 4 vectors of 4 floats per thread
+
+struct __attribute__((aligned(4))) F4 {  // 16 bytes at 4-byte alignment: one global_load_dwordx4
+  float x, y, z, w;
+};
+
+// kTileDx destination pixels per workgroup: 64 / 128 / 256 for scales up to 16 / 8 / 4, so that the strip (and with
+// it every thread's accumulators) is well filled at any scale.
+template <int kTileDx>
+__global__ __launch_bounds__(kTileThreads) void resize_area_tiled_kernel(const float* __restrict__ src,
+                                                                         float* __restrict__ dst, int sh, int sw, int dh,
+                                                                         int dw, double scale_y, double scale_x) {
+  __shared__ float strip[kTileFloats];
+  const int tid = threadIdx.x;
+  const int dx0 = blockIdx.x * kTileDx;
+  const int dx1 = dx0 + kTileDx < dw ? dx0 + kTileDx : dw;
+  const int dy = blockIdx.y;
+  const float* __restrict__ s = src + (size_t)blockIdx.z * sh * sw * 3;
+  const AreaSpan ay = area_span(dy, sh, scale_y);
+  const AreaSpan a_first = area_span(dx0, sw, scale_x), a_last = area_span(dx1 - 1, sw, scale_x);
+  const int sx_begin = a_first.first - (a_first.a_head != 0.0f ? 1 : 0);
+  const int sx_end = a_last.last + (a_last.a_tail != 0.0f ? 1 : 0);  // one past the last source pixel touched
+  const int n_floats = (sx_end - sx_begin) * 3;                         // <= kTileFloats by the launcher's choice
+  float acc[kTileVecs][4];
+#pragma unroll
+  for (int k = 0; k < kTileVecs; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0f;
+  const int has_head = ay.a_head != 0.0f ? 1 : 0, has_tail = ay.a_tail != 0.0f ? 1 : 0;
+  const int n_rows = has_head + (ay.last - ay.first) + has_tail;
+  for (int i = 0; i < n_rows; ++i) {
+    const int sy = ay.first - has_head + i;
+    const float beta = (i < has_head) ? ay.a_head : (sy < ay.last ? ay.a_full : ay.a_tail);
+    const float* __restrict__ row = s + ((size_t)sy * sw + sx_begin) * 3;
+#pragma unroll
+    for (int k = 0; k < kTileVecs; ++k) {
+      const int f = (tid + k * kTileThreads) * 4;
+      if (f + 4 <= n_floats) {
+        const F4 v = *reinterpret_cast<const F4*>(row + f);
+        acc[k][0] = fmaf(v.x, beta, acc[k][0]);
+        acc[k][1] = fmaf(v.y, beta, acc[k][1]);
+        acc[k][2] = fmaf(v.z, beta, acc[k][2]);
+        acc[k][3] = fmaf(v.w, beta, acc[k][3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (f + j < n_floats) acc[k][j] = fmaf(row[f + j], beta, acc[k][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kTileVecs; ++k) {
+    const int f = (tid + k * kTileThreads) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (f + j < n_floats) strip[f + j] = acc[k][j];
+  }
+  __syncthreads();
+  const int n_out = (dx1 - dx0) * 3;
+  for (int o = tid; o < n_out; o += kTileThreads) {
+    const int dxl = o / 3, ch = o - dxl * 3;
+    const AreaSpan ax = area_span(dx0 + dxl, sw, scale_x);
+    const float* col = strip + ch - sx_begin * 3;
+    float sum = 0.0f;
+    if (ax.a_head != 0.0f) sum = col[(ax.first - 1) * 3] * ax.a_head;
+    for (int sx = ax.first; sx < ax.last; ++sx) sum = fmaf(col[sx * 3], ax.a_full, sum);
+    if (ax.a_tail != 0.0f) sum = fmaf(col[ax.last * 3], ax.a_tail, sum);
+    dst[(((size_t)blockIdx.z * dh + dy) * dw + dx0) * 3 + o] = sum;
+  }
+}
+
 hipError_t launch_resize_area(const float* src, int sh, int sw, int batch, float* dst, int dh, int dw, hipStream_t st) {
   if (dh < 1 || dw < 1 || dh > sh || dw > sw || batch < 1 || dh > 65535 || batch > 65535) return hipErrorInvalidValue;
   // cv::resize forms the inverse scale first and inverts it again
   const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+  if (scale_x >= 2.0 && scale_x <= (double)kTileMaxScale) {
+    auto tiled = [&](auto kern, int tile_dx) {
+      const dim3 tgrid((dw + tile_dx - 1) / tile_dx, dh, batch);
+      hipLaunchKernelGGL(kern, tgrid, dim3(kTileThreads), 0, st, src, dst, sh, sw, dh, dw, scale_y, scale_x);
+    };
+    if (scale_x <= 4.0) {
+      tiled(resize_area_tiled_kernel<256>, 256);
+    } else if (scale_x <= 8.0) {
+      tiled(resize_area_tiled_kernel<128>, 128);
+    } else {
+      tiled(resize_area_tiled_kernel<64>, 64);
+    }
+    return hipGetLastError();
+  }
   const dim3 grid((dw + 63) / 64, dh, batch);
   if (scale_y >= 8.0) {
     hipLaunchKernelGGL(resize_area_kernel<8>, grid, dim3(512), 0, st, src, dst, sh, sw, dh, dw, scale_y, scale_x);
