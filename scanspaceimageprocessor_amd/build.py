@@ -60,7 +60,7 @@ def build(force=False, verbose=False, extra_flags=()):
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB, *objs],
+        r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-pthread", "-o", LIB, *objs],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

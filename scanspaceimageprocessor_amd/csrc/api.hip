@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 
 #include "ss_internal.h"
 
@@ -237,6 +238,39 @@ int ensure_pinned(ss_ctx* c) {
   return SS_OK;
 }
 
+// Host side of the staging copies.  One thread moves ~10-15 GB/s, PCIe takes ~50: a few helper threads per
+// chunk bring the pageable <-> pinned copy up to the link rate (measured on the MI355X host: 288 MB in 10.1 ms
+// with one thread, 5.6 ms with four).  SS_HOST_COPY_THREADS overrides the count (1 = no helpers).
+int host_copy_threads() {
+  static const int n = [] {
+    const char* e = getenv("SS_HOST_COPY_THREADS");
+    int x = e ? atoi(e) : 4;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && x > (int)hw) x = (int)hw;
+    return x < 1 ? 1 : (x > 16 ? 16 : x);
+  }();
+  return n;
+}
+
+void parallel_memcpy(void* dst, const void* src, size_t n) {
+  const int threads = n >= ((size_t)4 << 20) ? host_copy_threads() : 1;
+  if (threads == 1) {
+    memcpy(dst, src, n);
+    return;
+  }
+  const size_t part = ((n + threads - 1) / threads + 4095) & ~(size_t)4095;
+  std::thread pool[16];
+  int started = 0;
+  for (int t = 1; t < threads; ++t) {
+    const size_t o = (size_t)t * part;
+    if (o >= n) break;
+    const size_t len = n - o < part ? n - o : part;
+    pool[started++] = std::thread([=] { memcpy((char*)dst + o, (const char*)src + o, len); });
+  }
+  memcpy(dst, src, part < n ? part : n);
+  for (int t = 0; t < started; ++t) pool[t].join();
+}
+
 int copy_h2d(ss_ctx* c, void* dst, const void* src, size_t bytes) {
   int rc = ensure_pinned(c);
   if (rc) return rc;
@@ -245,7 +279,7 @@ int copy_h2d(ss_ctx* c, void* dst, const void* src, size_t bytes) {
   while (off < bytes) {
     const size_t n = bytes - off < kStageBytes ? bytes - off : kStageBytes;
     SS_HIP(c, hipEventSynchronize(c->pinned_free[b]));
-    memcpy(c->pinned[b], (const char*)src + off, n);
+    parallel_memcpy(c->pinned[b], (const char*)src + off, n);
     SS_HIP(c, hipMemcpyAsync((char*)dst + off, c->pinned[b], n, hipMemcpyHostToDevice, c->stream));
     SS_HIP(c, hipEventRecord(c->pinned_free[b], c->stream));
     off += n;
@@ -271,7 +305,7 @@ int copy_d2h(ss_ctx* c, void* dst, const void* src, size_t bytes) {
       bi ^= 1;
     }
     SS_HIP(c, hipEventSynchronize(c->pinned_free[bd]));
-    memcpy((char*)dst + off_done, c->pinned[bd], len[bd]);
+    parallel_memcpy((char*)dst + off_done, c->pinned[bd], len[bd]);
     off_done += len[bd];
     len[bd] = 0;
     bd ^= 1;

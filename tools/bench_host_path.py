@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Wall time of the host-buffer entry points on one 24 MP image (numpy in, numpy out): what a caller of the
+drop-in Python functions sees.  PCIe and host memory bound; never the benchmark's headline value."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scanspaceimageprocessor_amd import default_context
+from scanspaceimageprocessor_amd.chain import make_desc
+from scanspaceimageprocessor_amd.ImageProcessor import editingTools as et
+
+H, W = 4000, 6000
+rng = np.random.default_rng(0)
+img = (rng.random((H, W, 3), dtype=np.float32) ** 2.2 * 0.9).astype(np.float32)
+ctx = default_context()
+
+
+def timeit(name, fn, reps=5):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    print(f"{name:52s} {t * 1e3:8.1f} ms  {H * W / 1e6 / t:8.0f} MP/s", flush=True)
+
+
+ccm = (np.eye(3) * 0.9 + 0.03, 1, 3)
+d16 = make_desc(H, W, 1, ccm=ccm, gains=[1.1], usm=(40.0, 1.0, 0.0), final_clip=True, out="u16")
+d32 = make_desc(H, W, 1, ccm=ccm, gains=[1.1], final_clip=True, out="f32")
+timeit("ss_chain_run_host ccm+gain+usm -> u16 (288 MB in, 144 out)", lambda: ctx.chain_run_host(d16, img))
+timeit("ss_chain_run_host ccm+gain -> f32 (288 MB in, 288 out)", lambda: ctx.chain_run_host(d32, img))
+timeit("editingTools.adjust_sharpen (f32 in, f32 out)", lambda: et.adjust_sharpen(img, 40.0, 1.0, 0.0))
+timeit("numpy copy of the image, for scale", lambda: img.copy())

@@ -14,5 +14,5 @@ for f in chain usm stats resize mask api; do
   fi
 done
 wait
-hipcc -shared -fPIC --offload-arch=gfx950 -o ../variants/libscanspace_hip.$name.so build/$name/*.o
+hipcc -shared -fPIC --offload-arch=gfx950 -pthread -o ../variants/libscanspace_hip.$name.so build/$name/*.o
 echo built ../variants/libscanspace_hip.$name.so
