@@ -246,45 +246,40 @@ class ImageCorrectionWorker:
         h, w, _ = img.shape
         kind = self._out_kind(self.output_format)
         kw = self.chain_stages(img_path)
-        src = ctx.malloc(img.nbytes)
-        dst = ctx.malloc(img.nbytes)
-        neg = ctx.malloc(_lib.SS_NEG_PARAM_STRIDE * 4) if self.negative_mode else None
-        try:
-            ctx.upload(src, img)
-            if self.negative_mode:
-                ctx.negative_params(src, h, w, 1, self.negative_low_pct, self.negative_high_pct,
-                                    editingTools.NUMPY_LEGACY_PERCENTILE, neg)
-                kw.update(neg=True, neg_params_dev=neg)
-            encoded = np.empty(img.shape, dtype=_lib.OUT_DTYPES[kind])
-            if getattr(self, "export_masked", False):
-                # reference order (imageProcessorWorker.py:902-912): chain -> _apply_masking -> encode.  The chain
-                # leaves the clipped linear image in `dst`, the masking zeroes regions in place, and the encode
-                # (a chain with no stage) writes into `src`, whose contents are no longer needed.
-                ctx.chain_run(make_desc(h, w, 1, out="f32", **kw), src, dst)
-                self._apply_masking_device(ctx, dst, h, w)
-                ctx.chain_run(make_desc(h, w, 1, out=kind), dst, src)
-                ctx.download(encoded, src)
-                if encoded.dtype == np.uint8:
-                    preview = encoded
-                else:
-                    preview = np.empty(img.shape, dtype=np.uint8)
-                    ctx.chain_run(make_desc(h, w, 1, out="u8_linear"), dst, src)
-                    ctx.download(preview, src)
-                return encoded, preview
-            ctx.chain_run(make_desc(h, w, 1, out=kind, **kw), src, dst)
-            ctx.download(encoded, dst)
+        # buffers stay with the thread's context from image to image
+        src = ctx.workspace("worker.src", img.nbytes)
+        dst = ctx.workspace("worker.dst", img.nbytes)
+        neg = ctx.workspace("worker.neg", _lib.SS_NEG_PARAM_STRIDE * 4) if self.negative_mode else None
+        ctx.upload(src, img)
+        if self.negative_mode:
+            ctx.negative_params(src, h, w, 1, self.negative_low_pct, self.negative_high_pct,
+                                editingTools.NUMPY_LEGACY_PERCENTILE, neg)
+            kw.update(neg=True, neg_params_dev=neg)
+        encoded = np.empty(img.shape, dtype=_lib.OUT_DTYPES[kind])
+        if getattr(self, "export_masked", False):
+            # reference order (imageProcessorWorker.py:902-912): chain -> _apply_masking -> encode.  The chain
+            # leaves the clipped linear image in `dst`, the masking zeroes regions in place, and the encode
+            # (a chain with no stage) writes into `src`, whose contents are no longer needed.
+            ctx.chain_run(make_desc(h, w, 1, out="f32", **kw), src, dst)
+            self._apply_masking_device(ctx, dst, h, w)
+            ctx.chain_run(make_desc(h, w, 1, out=kind), dst, src)
+            ctx.download(encoded, src)
             if encoded.dtype == np.uint8:
                 preview = encoded
             else:
                 preview = np.empty(img.shape, dtype=np.uint8)
-                ctx.chain_run(make_desc(h, w, 1, out="u8_linear", **kw), src, dst)
-                ctx.download(preview, dst)
+                ctx.chain_run(make_desc(h, w, 1, out="u8_linear"), dst, src)
+                ctx.download(preview, src)
             return encoded, preview
-        finally:
-            ctx.free(src)
-            ctx.free(dst)
-            if neg:
-                ctx.free(neg)
+        ctx.chain_run(make_desc(h, w, 1, out=kind, **kw), src, dst)
+        ctx.download(encoded, dst)
+        if encoded.dtype == np.uint8:
+            preview = encoded
+        else:
+            preview = np.empty(img.shape, dtype=np.uint8)
+            ctx.chain_run(make_desc(h, w, 1, out="u8_linear", **kw), src, dst)
+            ctx.download(preview, dst)
+        return encoded, preview
 
     # ------------------------------------------------------------------ masking
 
@@ -294,13 +289,10 @@ class ImageCorrectionWorker:
         """``_apply_masking`` (imageProcessorWorker.py:979-1030) on an image resident on the GPU, in place."""
         shadow_limit = getattr(self, "shadow_limit", 0.05)
         highlight_limit = getattr(self, "highlight_limit", 0.98)
-        count_dev = ctx.malloc(8)
-        try:
-            ctx.mask_regions(img_dev, h, w, 1, shadow_limit, highlight_limit, self.MASK_MIN_AREA, count_dev)
-            count = np.zeros(1, dtype=np.uint64)
-            ctx.download(count, count_dev)
-        finally:
-            ctx.free(count_dev)
+        count_dev = ctx.workspace("worker.mask_count", 8)
+        ctx.mask_regions(img_dev, h, w, 1, shadow_limit, highlight_limit, self.MASK_MIN_AREA, count_dev)
+        count = np.zeros(1, dtype=np.uint64)
+        ctx.download(count, count_dev)
         self.signals.log.emit(
             f"[Export Masked] Masked {int(count[0])} pixels (min area={self.MASK_MIN_AREA}) "
             f"with limits shadow<={shadow_limit:.2f}, highlight>={highlight_limit:.2f}"
@@ -312,13 +304,10 @@ class ImageCorrectionWorker:
         ctx = default_context()
         arr = np.ascontiguousarray(corrected, dtype=np.float32)
         h, w, _ = arr.shape
-        buf = ctx.malloc(arr.nbytes)
-        try:
-            ctx.upload(buf, arr)
-            self._apply_masking_device(ctx, buf, h, w)
-            ctx.download(arr, buf)
-        finally:
-            ctx.free(buf)
+        buf = ctx.workspace("worker.dst", arr.nbytes)
+        ctx.upload(buf, arr)
+        self._apply_masking_device(ctx, buf, h, w)
+        ctx.download(arr, buf)
         if arr is not corrected and isinstance(corrected, np.ndarray) and corrected.dtype == np.float32 \
                 and corrected.flags.writeable:
             corrected[...] = arr

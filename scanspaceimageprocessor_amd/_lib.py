@@ -159,6 +159,9 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            for ptr, _ in getattr(self, "_workspaces", {}).values():
+                self.lib.ss_free(self.handle, C.c_void_p(ptr))
+            self._workspaces = {}
             self.lib.ss_ctx_destroy(self.handle)
             self.handle = None
 
@@ -200,6 +203,22 @@ class Context:
 
     def free(self, ptr):
         self.check(self.lib.ss_free(self.handle, C.c_void_p(ptr)))
+
+    def workspace(self, tag, nbytes):
+        """A device buffer of at least ``nbytes`` that stays with the context under ``tag`` (grown when a larger
+        one is asked for, released by ``close``): callers that process image after image on one thread reuse it
+        instead of paying an allocation and a device-wide synchronising free per image."""
+        ws = self.__dict__.setdefault("_workspaces", {})
+        have = ws.get(tag)
+        if have is not None and have[1] >= nbytes:
+            return have[0]
+        if have is not None:
+            self.sync()
+            self.free(have[0])
+            del ws[tag]
+        ptr = self.malloc(nbytes)
+        ws[tag] = (ptr, int(nbytes))
+        return ptr
 
     def upload(self, dst_dev, arr):
         arr = np.ascontiguousarray(arr)

@@ -36,3 +36,14 @@ timeit("ss_chain_run_host ccm+gain+usm -> u16 (288 MB in, 144 out)", lambda: ctx
 timeit("ss_chain_run_host ccm+gain -> f32 (288 MB in, 288 out)", lambda: ctx.chain_run_host(d32, img))
 timeit("editingTools.adjust_sharpen (f32 in, f32 out)", lambda: et.adjust_sharpen(img, 40.0, 1.0, 0.0))
 timeit("numpy copy of the image, for scale", lambda: img.copy())
+
+from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as ipw
+
+M_R = 0.03 + 0.87 * np.random.default_rng(7).random((24, 3))
+M_T = (M_R @ (np.eye(3) * 0.95 + 0.02).T).astype(np.float32)
+ipw.set_reference_swatches(M_R)
+for fmt, depth, masked in ((".tiff", 16, False), (".jpg", 8, False), (".tiff", 16, True)):
+    w = ipw.ImageCorrectionWorker(["a.nef"], M_T, "/tmp", None, output_format=fmt, tiff_bitdepth=depth, shadow_adj=10.0,
+                                  export_masked=masked)
+    timeit(f"worker.process_array chart mode -> {fmt} {depth}-bit{' masked' if masked else ''} (+ 8-bit preview)",
+           lambda: w.process_array(img, "a.nef"))
