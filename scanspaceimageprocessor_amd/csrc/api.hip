@@ -84,20 +84,6 @@ int grow(ss_ctx* c, void** p, size_t* have, size_t need) {
   return SS_OK;
 }
 
-void invert3x3(const double m[9], double inv[9]) {
-  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-  inv[0] = (e * i - f * h) / det;
-  inv[1] = (c * h - b * i) / det;
-  inv[2] = (b * f - c * e) / det;
-  inv[3] = (f * g - d * i) / det;
-  inv[4] = (a * i - c * g) / det;
-  inv[5] = (c * d - a * f) / det;
-  inv[6] = (d * h - e * g) / det;
-  inv[7] = (b * g - a * h) / det;
-  inv[8] = (a * e - b * d) / det;
-}
-
 bool cheung_terms_ok(int t) {
   switch (t) {
     case 3: case 5: case 7: case 8: case 10: case 11: case 14: case 16: case 17: case 19: case 20: case 22:
@@ -210,17 +196,6 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
   if (d->out_kind < SS_OUT_F32_LINEAR || d->out_kind > SS_OUT_U8_LINEAR)
     return fail(c, SS_ERR_INVALID, "unknown out_kind %d", d->out_kind);
 
-  // sRGB <-> XYZ (colour's sRGB colourspace: the published 4-digit matrix and its numerical inverse)
-  // folded with the D65 white of XYZ_to_Lab / Lab_to_XYZ: xy = (0.3127, 0.3290)
-  const double M[9] = {0.4124, 0.3576, 0.1805, 0.2126, 0.7152, 0.0722, 0.0193, 0.1192, 0.9505};
-  double Minv[9];
-  invert3x3(M, Minv);
-  const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
-  for (int r = 0; r < 3; ++r)
-    for (int k = 0; k < 3; ++k) {
-      P->m_fwd[r * 3 + k] = (float)(M[r * 3 + k] / white[r]);
-      P->m_inv[r * 3 + k] = (float)(Minv[r * 3 + k] * white[k]);
-    }
   return SS_OK;
 }
 

@@ -46,14 +46,38 @@ struct ChainParams {
   int32_t lab_io;
   int32_t final_clip;
 
-  // sRGB -> XYZ rows pre-divided by the D65 white, and XYZ -> sRGB columns pre-multiplied by it
-  float m_fwd[9];
-  float m_inv[9];
-
   // Full 3 x T table for T > 3, as [t] = {row R, row G, row B, 0}.  Kept LAST and only ever read with a
   // runtime index (staged into LDS at kernel start) so that it never occupies scalar registers.
   float ccm_full[SS_MAX_CCM_TERMS][4];
 };
+
+// sRGB <-> XYZ of colour-science's sRGB colourspace (the published 4-digit matrix and its numerical inverse),
+// folded with the D65 white (xy = 0.3127, 0.3290) of XYZ_to_Lab / Lab_to_XYZ: `fwd` rows are divided by the
+// white, `inv` columns multiplied by it.  Compile-time constants: as kernel arguments they (and the register
+// pairs packed arithmetic wants for them) crowded the scalar register file.
+struct LabMatrices {
+  float fwd[9];
+  float inv[9];
+};
+
+constexpr LabMatrices make_lab_matrices() {
+  const double m[9] = {0.4124, 0.3576, 0.1805, 0.2126, 0.7152, 0.0722, 0.0193, 0.1192, 0.9505};
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                         (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                         (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
+  LabMatrices o{};
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 3; ++k) {
+      o.fwd[r * 3 + k] = (float)(m[r * 3 + k] / white[r]);
+      o.inv[r * 3 + k] = (float)(inv[r * 3 + k] * white[k]);
+    }
+  return o;
+}
+
+constexpr LabMatrices kLab = make_lab_matrices();
 
 // symmetric tap lookup with a compile-time index
 template <int R>
@@ -156,9 +180,9 @@ __device__ __forceinline__ V lab_finv(V f) {
 template <class V>
 __device__ __forceinline__ LabT<V> rgb_to_lab(const PxT<V> p, const ChainParams& P) {
   const V r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
-  const V fx = lab_f(mad<V>(P.m_fwd[0], r, mad<V>(P.m_fwd[1], g, b * P.m_fwd[2])));
-  const V fy = lab_f(mad<V>(P.m_fwd[3], r, mad<V>(P.m_fwd[4], g, b * P.m_fwd[5])));
-  const V fz = lab_f(mad<V>(P.m_fwd[6], r, mad<V>(P.m_fwd[7], g, b * P.m_fwd[8])));
+  const V fx = lab_f(mad<V>(kLab.fwd[0], r, mad<V>(kLab.fwd[1], g, b * kLab.fwd[2])));
+  const V fy = lab_f(mad<V>(kLab.fwd[3], r, mad<V>(kLab.fwd[4], g, b * kLab.fwd[5])));
+  const V fz = lab_f(mad<V>(kLab.fwd[6], r, mad<V>(kLab.fwd[7], g, b * kLab.fwd[8])));
   LabT<V> o;
   o.L = mad<V>(fy, 116.0f, -16.0f);
   o.a = (fx - fy) * 500.0f;
@@ -174,9 +198,9 @@ __device__ __forceinline__ PxT<V> lab_to_rgb(const LabT<V> q, const ChainParams&
   const V fz = mad<V>(q.b, -1.0f / 200.0f, fy);
   const V x = lab_finv(fx), y = lab_finv(fy), z = lab_finv(fz);
   PxT<V> o;
-  o.r = clamp01(srgb_encode(mad<V>(P.m_inv[0], x, mad<V>(P.m_inv[1], y, z * P.m_inv[2]))));
-  o.g = clamp01(srgb_encode(mad<V>(P.m_inv[3], x, mad<V>(P.m_inv[4], y, z * P.m_inv[5]))));
-  o.b = clamp01(srgb_encode(mad<V>(P.m_inv[6], x, mad<V>(P.m_inv[7], y, z * P.m_inv[8]))));
+  o.r = clamp01(srgb_encode(mad<V>(kLab.inv[0], x, mad<V>(kLab.inv[1], y, z * kLab.inv[2]))));
+  o.g = clamp01(srgb_encode(mad<V>(kLab.inv[3], x, mad<V>(kLab.inv[4], y, z * kLab.inv[5]))));
+  o.b = clamp01(srgb_encode(mad<V>(kLab.inv[6], x, mad<V>(kLab.inv[7], y, z * kLab.inv[8]))));
   return o;
 }
 
@@ -197,9 +221,9 @@ struct LabFT {
 template <class V>
 __device__ __forceinline__ LabFT<V> linear_to_labf(const PxT<V> lin, const ChainParams& P) {
   LabFT<V> f;
-  f.fx = lab_f(mad<V>(P.m_fwd[0], lin.r, mad<V>(P.m_fwd[1], lin.g, lin.b * P.m_fwd[2])));
-  f.fy = lab_f(mad<V>(P.m_fwd[3], lin.r, mad<V>(P.m_fwd[4], lin.g, lin.b * P.m_fwd[5])));
-  f.fz = lab_f(mad<V>(P.m_fwd[6], lin.r, mad<V>(P.m_fwd[7], lin.g, lin.b * P.m_fwd[8])));
+  f.fx = lab_f(mad<V>(kLab.fwd[0], lin.r, mad<V>(kLab.fwd[1], lin.g, lin.b * kLab.fwd[2])));
+  f.fy = lab_f(mad<V>(kLab.fwd[3], lin.r, mad<V>(kLab.fwd[4], lin.g, lin.b * kLab.fwd[5])));
+  f.fz = lab_f(mad<V>(kLab.fwd[6], lin.r, mad<V>(kLab.fwd[7], lin.g, lin.b * kLab.fwd[8])));
   return f;
 }
 
@@ -232,9 +256,9 @@ __device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f
   // (a wave-uniform shortcut for "every pixel on the cubic segment" costs as much to decide as it saves)
   const V dx = finv_delta_any(f.fx, dfx), dy = finv_delta_any(f.fy, dfy), dz = finv_delta_any(f.fz, dfz);
   PxT<V> o;
-  o.r = clamp01(srgb_encode(mad<V>(P.m_inv[0], dx, mad<V>(P.m_inv[1], dy, mad<V>(P.m_inv[2], dz, lin.r)))));
-  o.g = clamp01(srgb_encode(mad<V>(P.m_inv[3], dx, mad<V>(P.m_inv[4], dy, mad<V>(P.m_inv[5], dz, lin.g)))));
-  o.b = clamp01(srgb_encode(mad<V>(P.m_inv[6], dx, mad<V>(P.m_inv[7], dy, mad<V>(P.m_inv[8], dz, lin.b)))));
+  o.r = clamp01(srgb_encode(mad<V>(kLab.inv[0], dx, mad<V>(kLab.inv[1], dy, mad<V>(kLab.inv[2], dz, lin.r)))));
+  o.g = clamp01(srgb_encode(mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, lin.g)))));
+  o.b = clamp01(srgb_encode(mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, lin.b)))));
   return o;
 }
 
@@ -593,8 +617,8 @@ template <bool PLAIN = false, class V = float>
 __device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const V Lb, const ChainParams& P) {
   LabFT<V> f;
   f.fy = mad<V>(Ln, 100.0f / 116.0f, 16.0f / 116.0f);
-  f.fx = lab_f(mad<V>(P.m_fwd[0], lin.r, mad<V>(P.m_fwd[1], lin.g, lin.b * P.m_fwd[2])));
-  f.fz = lab_f(mad<V>(P.m_fwd[6], lin.r, mad<V>(P.m_fwd[7], lin.g, lin.b * P.m_fwd[8])));
+  f.fx = lab_f(mad<V>(kLab.fwd[0], lin.r, mad<V>(kLab.fwd[1], lin.g, lin.b * kLab.fwd[2])));
+  f.fz = lab_f(mad<V>(kLab.fwd[6], lin.r, mad<V>(kLab.fwd[7], lin.g, lin.b * kLab.fwd[8])));
   V um = Ln - Lb;
   if (!PLAIN && P.usm_thr > 0.0f) {
     const V es = vabs(um);

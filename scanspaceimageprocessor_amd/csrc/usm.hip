@@ -444,7 +444,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         const Px p = front<CCMC, true, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M);
         if (!PLAIN && P.lab_io) return Slot{p.r * 0.01f, F3{p.r, p.g, p.b}};
         const float r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
-        const float fy = lab_f(fmaf(P.m_fwd[3], r, fmaf(P.m_fwd[4], g, b * P.m_fwd[5])));
+        const float fy = lab_f(fmaf(kLab.fwd[3], r, fmaf(kLab.fwd[4], g, b * kLab.fwd[5])));
         return Slot{fmaf(fy, 116.0f, -16.0f) * 0.01f, F3{r, g, b}};
 #endif
       };
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
           return;
         }
         const v2f r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
-        const v2f fy = lab_f(mad<v2f>(P.m_fwd[3], r, mad<v2f>(P.m_fwd[4], g, b * P.m_fwd[5])));
+        const v2f fy = lab_f(mad<v2f>(kLab.fwd[3], r, mad<v2f>(kLab.fwd[4], g, b * kLab.fwd[5])));
         const v2f Ln = mad<v2f>(fy, 116.0f, -16.0f) * 0.01f;
         qa = Slot{Ln.x, F3{r.x, g.x, b.x}};
         qb = Slot{Ln.y, F3{r.y, g.y, b.y}};
