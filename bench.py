@@ -38,9 +38,9 @@ HBM_PEAK_GBS = 8000.0
 ALGO_BYTES_PER_PX = 18.0  # 12 in (float32 RGB) + 6 out (uint16 RGB)
 # HBM traffic of the unsharp-mask kernel per pixel, from the rocprofv3 PMC passes kept under profiles/
 # (FETCH_SIZE doubled as gfx950 needs, calibrated on the pointwise kernel's known 12 B/px; WRITE_SIZE as read):
-# 14.69 B/px fetched (tile halos are read again) + 6.00 B/px written.  It cannot be collected inside this
+# 14.85 B/px fetched (tile halos are read again) + 6.00 B/px written.  It cannot be collected inside this
 # process; re-measure it when the kernel's tiling changes.
-MEASURED_TRAFFIC_BYTES_PER_PX = 20.7
+MEASURED_TRAFFIC_BYTES_PER_PX = 20.9
 
 
 def synthetic_swatches():
@@ -209,7 +209,7 @@ def main():
                 "bound": "hbm", "kernel": "usm_kernel<6, CCM_LIN3, U16_SRGB, plain>", "achieved": round(achieved_gbs, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                 "traffic": round(MEASURED_TRAFFIC_BYTES_PER_PX * px_per_launch),
-                "traffic_note": "bytes per launch = 20.7 B/px (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) x px_per_launch",
+                "traffic_note": "bytes per launch = 20.9 B/px (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) x px_per_launch",
                 "algorithmic_bytes_per_px": ALGO_BYTES_PER_PX,
                 "px_per_launch": px_per_launch, "kernel_ms": round(kernel_ms, 4),
             },
