@@ -33,10 +33,6 @@ constexpr int USM_WAVES_PER_SIMD = 2 * USM_NT / 256;  // two workgroups per CU
 #define USM_SYNC() __syncthreads()
 #endif
 
-#ifndef SS_USM_PREFETCH
-#define SS_USM_PREFETCH 13  // phase-1 pixels in flight per thread (13 = the whole tile at r = 6)
-#endif
-
 // UNIT: the values are known to lie in [0, 1] (no clamp needed before the truncating conversion)
 template <int OUT, bool UNIT>
 __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int y, int x, const Px o0, const Px o1) {
@@ -437,7 +433,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         float Ln;
         F3 c;  // what phase 3 needs of the pixel: linear RGB, or (L, a, b) when the data is Lab
       };
-      auto slot_eval = [&](const F3 px, bool need_c) -> Slot {
+      auto slot_eval = [&](const F3 px) -> Slot {
 #ifdef SS_ABL_NO_P1  // timing experiment: phase 1 without its arithmetic
         return Slot{px.x, px};
 #else
@@ -476,7 +472,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       auto slot_compute = [&](const F3 px, int ly, int lx) {
         const int cy = ly - r, cx = lx - r;
         const bool own = (unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW;
-        const Slot q = slot_eval(px, own);
+        const Slot q = slot_eval(px);
         Lt[ly * PW + lx] = q.Ln;
         if (own) plane_write(cy, cx, q.c);
       };
@@ -496,7 +492,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         // packing moves to amortise (measured: 218 vs 210 VALU instructions per pixel)
         if constexpr (PLAIN) {
 #pragma unroll
-          for (int k = 0; k < MAIN; ++k) qs[k] = slot_eval(v[k], true);
+          for (int k = 0; k < MAIN; ++k) qs[k] = slot_eval(v[k]);
         } else {
 #pragma unroll
           for (int k = 0; k < MAIN; k += 2) slot_eval2(v[k], v[k + 1], qs[k], qs[k + 1]);
@@ -513,7 +509,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
             late_c[k - (MAIN - DEFER)] = q.c;
           }
         }
-        if (l.s_on) Lt[(2 * r + l.s_row) * PW + l.s_lx] = slot_eval(v[MAIN], false).Ln;
+        if (l.s_on) Lt[(2 * r + l.s_row) * PW + l.s_lx] = slot_eval(v[MAIN]).Ln;
       } else {
         for (int idx = tid; idx < n_new; idx += NT) {
           const int ly = idx / PWv, lx = idx - ly * PWv;
