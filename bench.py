@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--amount", type=float, default=1.0, help="unsharp-mask amount (BASELINE: 1.0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
+                    help="config2 = BASELINE.json configs[1] (default, the headline); config5 = the dataset-normalisation "
+                         "scaling case: thumbnail statistics -> all-gather -> multipliers -> CCM + gain + sRGB, float32 "
+                         "out, 128 images per GPU unless --batch is given")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +119,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    config5 = args.workload == "config5"
+    if config5 and args.batch == 64:
+        args.batch = 128
     B = args.batch
     n_total = B * world
     first, count = shard_range(n_total, rank, world)
@@ -131,7 +138,7 @@ def main():
         img.pow_(2.2).mul_(0.9 * float(scales[first + i])).clamp_(0.0, 1.0)
         images[i] = img
         del img
-    out = torch.empty((B, H, W, 3), dtype=torch.int16, device=dev)  # uint16 payload
+    out = torch.empty((B, H, W, 3), dtype=torch.float32 if config5 else torch.int16, device=dev)  # int16 = uint16 payload
 
     ctx = Context(local_rank)
     # the 512-pixel thumbnails the exposure statistics read: the loader's area-average downscale, on the device
@@ -149,8 +156,11 @@ def main():
 
     M_T, M_R = synthetic_swatches()
     ccm = matrix_colour_correction(M_T, M_R)  # Cheung 2004, 3 terms: the reference's only call form
-    desc = make_desc(H, W, B, ccm=ccm, gains=[1.0], gain0_dev=gains.data_ptr(), usm=(args.amount, 2.0, 0.0),
-                     final_clip=True, out="u16")
+    if config5:
+        desc = make_desc(H, W, B, ccm=ccm, gains=[1.0], gain0_dev=gains.data_ptr(), final_clip=True, out="f32_srgb")
+    else:
+        desc = make_desc(H, W, B, ccm=ccm, gains=[1.0], gain0_dev=gains.data_ptr(), usm=(args.amount, 2.0, 0.0),
+                         final_clip=True, out="u16")
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -182,13 +192,18 @@ def main():
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     px_per_launch = float(B) * H * W
-    achieved_gbs = ALGO_BYTES_PER_PX * px_per_launch / (kernel_ms * 1e-3) / 1e9
+    algo_bytes = 24.0 if config5 else ALGO_BYTES_PER_PX  # config5: 12 in + 12 out (float32)
+    achieved_gbs = algo_bytes * px_per_launch / (kernel_ms * 1e-3) / 1e9
     mp_total = n_total * H * W / 1e6 * args.steps
     value = mp_total / elapsed
 
     # sanity: the output must not be all zeros / all saturated (catches a silently skipped launch)
-    sample = out[0, ::400, ::600].to(torch.int32) & 0xFFFF
-    assert int(sample.max()) > 0 and int(sample.min()) < 65535, "implausible output"
+    if config5:
+        sample = out[0, ::400, ::600]
+        assert float(sample.max()) > 0.0 and float(sample.min()) < 1.0, "implausible output"
+    else:
+        sample = out[0, ::400, ::600].to(torch.int32) & 0xFFFF
+        assert int(sample.max()) > 0 and int(sample.min()) < 65535, "implausible output"
     g = gains.cpu().numpy()
     assert np.all(np.isfinite(g)) and abs(float(np.mean(g)) - 1.0) < 0.2, "implausible exposure multipliers"
 
@@ -199,22 +214,27 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{B}x24MP per GPU: exposure normalisation + Cheung-2004 3x3 CCM + gain + clip + unsharp "
-                            f"mask (radius 2, amount {args.amount:g}) + sRGB encode + 16-bit quantise "
-                            "(BASELINE.json configs[1])",
+                "workload": (f"{B}x24MP per GPU: exposure normalisation + Cheung-2004 3x3 CCM + gain + clip + sRGB encode, "
+                             "float32 out (the dataset-normalisation scaling case)") if config5 else
+                            (f"{B}x24MP per GPU: exposure normalisation + Cheung-2004 3x3 CCM + gain + clip + unsharp "
+                             f"mask (radius 2, amount {args.amount:g}) + sRGB encode + 16-bit quantise "
+                             "(BASELINE.json configs[1])"),
                 "images_per_gpu": B, "height": H, "width": W, "parallelism": f"image-sharded x{world}",
                 "collective": "all_gather of per-image brightness (RCCL)" if world > 1 else "none",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "usm_kernel<6, CCM_LIN3, U16_SRGB, plain>", "achieved": round(achieved_gbs, 1),
+                "bound": "hbm",
+                "kernel": "chain_kernel<CCM_LIN3, no S/H, F32_SRGB>" if config5 else "usm_kernel<6, CCM_LIN3, U16_SRGB, plain>",
+                "achieved": round(achieved_gbs, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                "traffic": round(MEASURED_TRAFFIC_BYTES_PER_PX * px_per_launch),
-                "traffic_note": "bytes per launch = 20.9 B/px (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) x px_per_launch",
-                "algorithmic_bytes_per_px": ALGO_BYTES_PER_PX,
+                "traffic": round((24.0 if config5 else MEASURED_TRAFFIC_BYTES_PER_PX) * px_per_launch),
+                "traffic_note": ("bytes per launch = 24.0 B/px" if config5 else "bytes per launch = 20.9 B/px")
+                                + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) x px_per_launch",
+                "algorithmic_bytes_per_px": algo_bytes,
                 "px_per_launch": px_per_launch, "kernel_ms": round(kernel_ms, 4),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not config5:
             line["cpu_baseline"] = cpu_baseline(args.amount)
         print(json.dumps(line), flush=True)
 
