@@ -32,24 +32,37 @@ __device__ __forceinline__ void store_one(void* dst_img, uint32_t px, const Px p
 }
 
 template <int CCMC, bool SH, int OUT>
-__global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const float* __restrict__ src,
+__global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, const float* __restrict__ src,
                                                     void* __restrict__ dst) {
   constexpr int G = OutTraits<OUT>::G;
   constexpr int K = 4 / G;  // groups per lane per trip: 4 pixels in flight per lane
   __shared__ float4 M[ccm_needs_table<CCMC> ? SS_MAX_CCM_TERMS : 1];
   if constexpr (ccm_needs_table<CCMC>) {
-    stage_ccm(P, M, threadIdx.x, 256);
+    stage_ccm(P_arg, M, threadIdx.x, 256);
     __syncthreads();
   }
   const int img = blockIdx.y;
-  const ImgParams ip = load_img_params(P, img);
-  const uint32_t n = (uint32_t)P.n_px;
+  const ImgParams ip = load_img_params(P_arg, img);
+  const uint32_t n = (uint32_t)P_arg.n_px;
+  // Chains with the shadows/highlights stage use more scalars than the register file holds.  They read the
+  // parameter block through a pointer to the kernel argument segment the compiler cannot see through, once
+  // per trip: scalar loads next to the uses instead of scalars parked in (and fetched back from) vector lanes.
+  auto params_now = [&]() -> const ChainParams& {
+    if constexpr (SH && !ccm_needs_table<CCMC>) {
+      typedef const __attribute__((address_space(4))) ChainParams* KernargParams;
+      KernargParams k = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(k));
+      return *(const ChainParams*)k;
+    }
+    return P_arg;
+  };
   const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * n * 3);
   char* d = reinterpret_cast<char*>(dst) + (size_t)img * n * 3 * OutTraits<OUT>::BYTES;
   const uint32_t n_groups = n / G;
   constexpr uint32_t CHUNK = 256 * K;
 
   for (uint32_t base = blockIdx.x * CHUNK; base < n_groups; base += gridDim.x * CHUNK) {
+    const ChainParams& P = params_now();
     F3 in[K][G] = {};
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -101,6 +114,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P, const f
     const uint32_t px = n_groups * G + threadIdx.x;
     if (px < n) {
       const F3 v = s[px];
+      const ChainParams& P = params_now();
       store_one<OUT>(d, px, finish<OUT, false, float>(front<CCMC, SH, false, float>(Px{v.x, v.y, v.z}, P, ip, M), P));
     }
   }

@@ -249,17 +249,25 @@ __device__ __forceinline__ V finv_delta_any(V f, V d) {
   return mad<V>(dm, 3.0f * T * T, dc * mad<V>(dc, dc, (c * c2) * 3.0f));
 }
 
-// clip(encode(linear + M_inv * (g(f + df) - g(f)))): what _lab_to_rgb returns for the edited pixel
+// linear + M_inv * (g(f + df) - g(f)): the edited pixel before _lab_to_rgb encodes and clips it
 template <class V>
-__device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy, const V dfz,
-                                              const ChainParams& P) {
+__device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy,
+                                                 const V dfz) {
   // (a wave-uniform shortcut for "every pixel on the cubic segment" costs as much to decide as it saves)
   const V dx = finv_delta_any(f.fx, dfx), dy = finv_delta_any(f.fy, dfy), dz = finv_delta_any(f.fz, dfz);
   PxT<V> o;
-  o.r = clamp01(srgb_encode(mad<V>(kLab.inv[0], dx, mad<V>(kLab.inv[1], dy, mad<V>(kLab.inv[2], dz, lin.r)))));
-  o.g = clamp01(srgb_encode(mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, lin.g)))));
-  o.b = clamp01(srgb_encode(mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, lin.b)))));
+  o.r = mad<V>(kLab.inv[0], dx, mad<V>(kLab.inv[1], dy, mad<V>(kLab.inv[2], dz, lin.r)));
+  o.g = mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, lin.g)));
+  o.b = mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, lin.b)));
   return o;
+}
+
+// clip(encode(.)) of it: what _lab_to_rgb returns for the edited pixel
+template <class V>
+__device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy, const V dfz,
+                                              const ChainParams& P) {
+  const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz);
+  return PxT<V>{clamp01(srgb_encode(o.r)), clamp01(srgb_encode(o.g)), clamp01(srgb_encode(o.b))};
 }
 
 // ---- colour correction ---------------------------------------------------------------------
@@ -511,8 +519,11 @@ __device__ __forceinline__ LabT<V> sh_on_lab(LabT<V> q, const ChainParams& P) {
 __device__ __forceinline__ float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ v2f med3(v2f x, v2f lo, v2f hi) { return v2f{med3(x.x, lo.x, hi.x), med3(x.y, lo.y, hi.y)}; }
 
-// RGB (sRGB-encoded, as the reference assumes) in and out: _rgb_to_lab, the edit, _lab_to_rgb
-template <class V>
+// RGB (sRGB-encoded, as the reference assumes) in and out: _rgb_to_lab, the edit, _lab_to_rgb.
+// DECODED = true returns the sRGB decoding of that result instead: decode(clip(encode(x), 0, 1)) is
+// clip(x, 0, 1) (encode is increasing and fixes 0 and 1), so a consumer that would decode the pixel again
+// - the next Lab edit - gets it without the encode/decode pair and without that pair's rounding.
+template <bool DECODED = false, class V>
 __device__ __forceinline__ PxT<V> sh_on_rgb(const PxT<V> p, const ChainParams& P) {
   const PxT<V> lin{srgb_decode(p.r), srgb_decode(p.g), srgb_decode(p.b)};
   const LabFT<V> f = linear_to_labf(lin, P);
@@ -526,7 +537,12 @@ __device__ __forceinline__ PxT<V> sh_on_rgb(const PxT<V> p, const ChainParams& P
     dfx = dfy - (f.fx - f.fy) * shrink;
     dfz = dfy + (f.fy - f.fz) * shrink;
   }
-  return shifted_rgb(lin, f, dfx, dfy, dfz, P);
+  if constexpr (DECODED) {
+    const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz);
+    return PxT<V>{clamp01(o.r), clamp01(o.g), clamp01(o.b)};
+  } else {
+    return shifted_rgb(lin, f, dfx, dfy, dfz, P);
+  }
 }
 
 // ---- stages 1-4 --------------------------------------------------------------------------------
@@ -579,11 +595,30 @@ __device__ __forceinline__ PxT<V> front(PxT<V> p, const ChainParams& P, const Im
         const LabT<V> q = sh_on_lab(LabT<V>{p.r, p.g, p.b}, P);
         p = PxT<V>{q.L, q.a, q.b};
       } else {
-        p = sh_on_rgb(p, P);
+        p = sh_on_rgb<false, V>(p, P);
       }
     }
   }
   return p;
+}
+
+// Stages 1-4 for a consumer that works on the decoded pixel (the sharpen stage): linear RGB for RGB data,
+// (L, a, b) unchanged for Lab data.
+template <int CCMC, bool PLAIN = false, class V = float>
+__device__ __forceinline__ PxT<V> front_decoded(PxT<V> p, const ChainParams& P, const ImgParams& ip,
+                                                const float4* __restrict__ M) {
+  p = front<CCMC, false, PLAIN, V>(p, P, ip, M);
+  if constexpr (!PLAIN) {
+    if (P.lab_io) {
+      if (P.sh) {
+        const LabT<V> q = sh_on_lab(LabT<V>{p.r, p.g, p.b}, P);
+        p = PxT<V>{q.L, q.a, q.b};
+      }
+      return p;
+    }
+    if (P.sh) return sh_on_rgb<true, V>(p, P);
+  }
+  return PxT<V>{srgb_decode(p.r), srgb_decode(p.g), srgb_decode(p.b)};
 }
 
 // ---- stage 5 pointwise part: unsharp mask on (Ln, blurred Ln) (editingTools.py:767-809) -------

@@ -158,6 +158,18 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
     l.s_on = t < 2 * r * TH;
     return l;
   };
+  // The parameter block as the kernel argument segment holds it, behind a pointer the compiler cannot see
+  // through: scalars read through it are loaded (scalar loads) in the phase that uses them instead of all
+  // living in scalar registers, spilled to vector lanes, across the whole walk.
+  auto params_now = [&]() -> const ChainParams& {
+    if constexpr (!PLAIN) {  // (the plain chain uses few enough parameters to keep them)
+      typedef const __attribute__((address_space(4))) ChainParams* KernargParams;
+      KernargParams k = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(k));
+      return *(const ChainParams*)k;
+    }
+    return P;
+  };
   // float4 moves per thread for the carried rows: 2r rows of Lt (PW floats) and of Ht (TW floats)
   constexpr int CARRY_MAX = (2 * SS_MAX_USM_RADIUS * ((USM_TW + 2 * SS_MAX_USM_RADIUS + 3) / 4 + USM_TW / 4) + NT - 1) / NT;
   constexpr int CARRY = R_T ? (2 * R_T * ((TW + 2 * R_T + 3) / 4 + TW / 4) + NT - 1) / NT : CARRY_MAX;
@@ -235,6 +247,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       const int x0 = cur.x0, y0 = cur.ty * TH;
       const bool first = cur.first;
       const bool more = pend.valid && !pend.first;  // the next tile continues this segment
+      const ChainParams& P = params_now();
       char* d = reinterpret_cast<char*>(dst) + (size_t)cur.img * P.n_px * 3 * OutTraits<OUT>::BYTES;
 
       // ---- phase 2: row pass over the rows phase 1 has just written ----
@@ -416,6 +429,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
     {
       // the last tile of a segment draws the workgroup's next segment; the ticket travels through LDS at
       // the barrier that closes phase 1
+      const ChainParams& P = params_now();
       const bool last_of_seg = cur.ty + 1 >= cur.ty_end;
       uint32_t drawn = 0;
       if (last_of_seg && tid == 0) drawn = atomicAdd(T.ticket, 1u);
@@ -437,9 +451,9 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #ifdef SS_ABL_NO_P1  // timing experiment: phase 1 without its arithmetic
         return Slot{px.x, px};
 #else
-        const Px p = front<CCMC, true, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M);
-        if (!PLAIN && P.lab_io) return Slot{p.r * 0.01f, F3{p.r, p.g, p.b}};
-        const float r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
+        const Px lin = front_decoded<CCMC, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M);
+        if (!PLAIN && P.lab_io) return Slot{lin.r * 0.01f, F3{lin.r, lin.g, lin.b}};
+        const float r = lin.r, g = lin.g, b = lin.b;
         const float fy = lab_f(fmaf(kLab.fwd[3], r, fmaf(kLab.fwd[4], g, b * kLab.fwd[5])));
         return Slot{fmaf(fy, 116.0f, -16.0f) * 0.01f, F3{r, g, b}};
 #endif
@@ -450,13 +464,13 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         qa = Slot{pa.x, pa};
         qb = Slot{pb.x, pb};
 #else
-        const Px2 p = front<CCMC, true, PLAIN, v2f>(Px2{v2f{pa.x, pb.x}, v2f{pa.y, pb.y}, v2f{pa.z, pb.z}}, P, ip, M);
+        const Px2 p = front_decoded<CCMC, PLAIN, v2f>(Px2{v2f{pa.x, pb.x}, v2f{pa.y, pb.y}, v2f{pa.z, pb.z}}, P, ip, M);
         if (!PLAIN && P.lab_io) {
           qa = Slot{p.r.x * 0.01f, F3{p.r.x, p.g.x, p.b.x}};
           qb = Slot{p.r.y * 0.01f, F3{p.r.y, p.g.y, p.b.y}};
           return;
         }
-        const v2f r = srgb_decode(p.r), g = srgb_decode(p.g), b = srgb_decode(p.b);
+        const v2f r = p.r, g = p.g, b = p.b;
         const v2f fy = lab_f(mad<v2f>(kLab.fwd[3], r, mad<v2f>(kLab.fwd[4], g, b * kLab.fwd[5])));
         const v2f Ln = mad<v2f>(fy, 116.0f, -16.0f) * 0.01f;
         qa = Slot{Ln.x, F3{r.x, g.x, b.x}};
