@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
   // parameter block through a pointer to the kernel argument segment the compiler cannot see through, once
   // per trip: scalar loads next to the uses instead of scalars parked in (and fetched back from) vector lanes.
   auto params_now = [&]() -> const ChainParams& {
-    if constexpr (SH && !ccm_needs_table<CCMC>) {
+    if constexpr (SH && !ccm_needs_table<CCMC>) {  // (no gain measured for the table-driven corrections)
       typedef const __attribute__((address_space(4))) ChainParams* KernargParams;
       KernargParams k = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(k));
@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
       const Px2 o2 = finish<OUT, false, v2f>(front<CCMC, SH, false, v2f>(pair_px(flat[q], flat[q + 1]), P, ip, M), P);
       res[q] = px_lo(o2);
       res[q + 1] = px_hi(o2);
+      // long term lists: one pair's arithmetic at a time keeps the register count down (282 -> 102 vector
+      // registers for the 22-term lists, i.e. one wave per SIMD -> four)
+      if constexpr (ccm_needs_table<CCMC>) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {

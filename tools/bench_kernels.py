@@ -65,7 +65,7 @@ def main():
 
     todo = args.configs.split(",")
     H, W, B = 4000, 6000, args.batch
-    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "5", "5b", "5c", "t", "m")):
+    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "1c", "5", "5b", "5c", "t", "m")):
         img = images(H, W, B)
         out = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
     if "1" in todo:
@@ -96,6 +96,12 @@ def main():
         ccm = matrix_colour_correction(M_T, M_R, method="Finlayson 2015", degree=3)
         d = make_desc(H, W, B, ccm=ccm, gains=[1.1], usm=(50.0, 2.0, 0.0), final_clip=True, out="u16")
         report("5c rootpoly(d3)+gain+usm(r2,a50)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "1c" in todo:  # colour corrections with long term lists (coefficient table in LDS), pointwise
+        for name, kw in (("cheung(22)", dict(method="Cheung 2004", terms=22)),
+                         ("rootpoly(d4)", dict(method="Finlayson 2015", degree=4))):
+            ccm = matrix_colour_correction(M_T, M_R, **kw)
+            d = make_desc(H, W, B, ccm=ccm, gains=[1.0], out="f32_srgb")
+            report(f"1c {name}+clip+srgb f32", H, W, B, 24, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
     if "t" in todo:  # preview / thumbnail producers: 24 MP -> 512 x 341 and -> 1 MP
         for name, (dw, dh) in (("512px thumbnail", (512, 341)), ("1 MP preview", (1224, 816))):
             small = torch.empty((B, dh, dw, 3), dtype=torch.float32, device=dev)
