@@ -247,7 +247,8 @@ int ss_resize_area_host(ss_ctx* ctx, const float* src_host, int32_t height, int3
  * candidates (cv2.connectedComponentsWithStats(mask, connectivity=8)) with an area of at least min_area pixels
  * (the reference hard-wires 200) are set to 0 in place.  img_dev: [batch][height][width][3] float32.
  * masked_count_dev: optional device uint64[batch], the number of pixels zeroed per image (the reference logs it).
- * The set of zeroed pixels is exactly the reference's for the same input values.  Asynchronous. */
+ * The set of zeroed pixels is exactly the reference's for the same input values.  Asynchronous.
+ * Limits: width <= 65535, height * width < 2^31, batch <= 65535. */
 int ss_mask_regions(ss_ctx* ctx, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
                     double highlight_limit, int32_t min_area, uint64_t* masked_count_dev);
 

@@ -551,12 +551,12 @@ int ss_mask_regions(ss_ctx* c, float* img_dev, int32_t height, int32_t width, in
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!img_dev) return fail(c, SS_ERR_INVALID, "img_dev must not be NULL");
-  if (height < 1 || width < 1 || batch < 1 || batch > 65535 || height > 65535 ||
+  if (height < 1 || width < 1 || batch < 1 || batch > 65535 || width > 65535 ||
       (int64_t)height * width > INT32_MAX)
     return fail(c, SS_ERR_INVALID, "bad image shape %d x %d x %d", batch, height, width);
   if (!(shadow_limit == shadow_limit) || !(highlight_limit == highlight_limit))
     return fail(c, SS_ERR_INVALID, "limits must not be NaN");
-  rc = grow(c, &c->ws_mask, &c->ws_mask_bytes, mask_workspace_bytes(batch, (int64_t)height * width));
+  rc = grow(c, &c->ws_mask, &c->ws_mask_bytes, mask_workspace_bytes(batch, height, width));
   if (rc) return rc;
   hipError_t e = launch_mask_regions(img_dev, height, width, batch, shadow_limit, highlight_limit, min_area, c->ws_mask,
                                      reinterpret_cast<unsigned long long*>(masked_count_dev), c->stream);

@@ -5,18 +5,23 @@
 // pixels is set to zero in the image.  The result is a set of pixels: it does not depend on how components
 // are numbered, so it is reproduced bit for bit.
 //
-// Connected components by union-find over row runs:
-//   mask_runs_kernel    one workgroup per image row: luminance test, then every candidate pixel gets the
-//                       index of the first pixel of its horizontal run (segmented max-scan along the row).
-//   mask_merge_kernel   runs of adjacent rows that touch (8-connectivity) are united, once per contact:
-//                       lock-free union with path halving.  Every write to a parent word in this kernel is an
+// Connected components by union-find over row runs.  The image is read once; everything after that works
+// on the list of runs (maximal horizontal stretches of candidate pixels), which for the masks this is made
+// for - a backdrop, a blown highlight - is a few entries per row:
+//   mask_runs_kernel    one workgroup per image row: luminance test, run starts and ends, the run list of
+//                       the row (run k of row y lives in slot y * cap + k, cap = ceil(w / 2) = the most runs
+//                       a row can hold).
+//   mask_merge_kernel   every run is united with the runs of the row above it touches (8-connectivity:
+//                       columns [start - 1, end + 1]), found by bisection in that row's sorted list.
+//                       Lock-free union with path halving.  Every write to a parent word in this kernel is an
 //                       atomicMin: parents only ever decrease, so no writer can undo another one's link
 //                       (plain stores, which reach memory late from a remote XCD's L2, did exactly that).
 //   mask_flatten_kernel pointer jumping, one launch per round until a round changes nothing: each word has
-//                       a single writer here, so plain stores are safe.  Afterwards every label is a root.
-//   mask_area_kernel    areas per root, one atomic per group of lanes that share a root.
-//   mask_apply_kernel   pixels whose component is large enough are zeroed and counted.
-// Labels are pixel indices inside their own image (int32: images up to 2^31 pixels).
+//                       a single writer here, so plain stores are safe.  Afterwards every parent is a root.
+//   mask_area_kernel    areas per root: run lengths summed per lane while the root stays the same, then
+//                       over the lanes of a wave that share a root, one atomic per distinct root.
+//   mask_apply_kernel   per row, the runs of components that are large enough are painted into a bitmap in
+//                       LDS, then the row's pixels under the bitmap are zeroed (coalesced) and counted.
 
 #include "ss_internal.h"
 
@@ -25,7 +30,7 @@ namespace ss {
 namespace {
 
 constexpr int kRowThreads = 256;
-constexpr int kPxPerThread = 4;
+constexpr int kPxPerThread = 8;
 constexpr int kChunk = kRowThreads * kPxPerThread;
 
 // np: 0.2126 * c0 + 0.7152 * c1 + 0.0722 * c2 on float64 data, no contraction
@@ -35,65 +40,97 @@ __device__ __forceinline__ bool is_candidate(const F3 p, double lo, double hi) {
   return lum <= lo || lum >= hi;
 }
 
-__device__ __forceinline__ int wave_scan_max(int v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(v, d);
-    if ((int)(threadIdx.x & 63) >= d) v = v > o ? v : o;
-  }
-  return v;
-}
+// The run lists of one image.  Slots are numbered inside the image: slot = y * cap + k.
+struct RunLists {
+  uint16_t* span;     // [slots][2]: first and last column of the run
+  int32_t* parent;    // [slots]
+  int32_t* area;      // [slots]
+  int32_t* rowcount;  // [h]
+};
 
-__global__ __launch_bounds__(kRowThreads) void mask_runs_kernel(const float* __restrict__ img, int32_t* __restrict__ label,
+struct MaskWork {
+  uint16_t* span;
+  int32_t* parent;
+  int32_t* area;
+  int32_t* rowcount;
+  int* flags;
+  int cap;
+  size_t slots;  // per image
+  __host__ __device__ RunLists image(int b, int h) const {
+    return RunLists{span + (size_t)b * slots * 2, parent + (size_t)b * slots, area + (size_t)b * slots,
+                    rowcount + (size_t)b * h};
+  }
+};
+
+// A run starts at a candidate pixel whose left neighbour is none and ends left of a non-candidate pixel whose
+// left neighbour is one: both are decided looking left only.  Column w (one past the row) is walked as a
+// non-candidate pixel so that a run touching the right border ends too.
+// A chunk is kPxPerThread stripes of 256 adjacent pixels, lane = pixel inside the stripe (loads of a wave are
+// contiguous).  The left flag comes from the neighbouring lane, across waves and stripes through LDS, across
+// chunks in a register; the number of a run inside its row is the count of starts to its left: lanes below
+// in the same wave (ballot), plus the totals of the waves and stripes before (LDS).
+__global__ __launch_bounds__(kRowThreads) void mask_runs_kernel(const float* __restrict__ img, const MaskWork work,
                                                                 int h, int w, double lo, double hi) {
-  __shared__ int wave_last[kRowThreads / 64];
-  __shared__ int carry_s;
+  constexpr int NW = kRowThreads / 64, P = kPxPerThread;
+  __shared__ int starts_of[P * NW];  // starts per (stripe, wave), in pixel order
+  __shared__ int edge_of[P * NW];    // candidate flag of the last pixel of each (stripe, wave)
   const int y = blockIdx.x, b = blockIdx.y;
-  const size_t row0 = ((size_t)b * h + y) * w;
-  const F3* __restrict__ src = reinterpret_cast<const F3*>(img) + row0;
-  int32_t* __restrict__ out = label + row0;
-  const int base_label = y * w;  // labels are indices within the image
+  const F3* __restrict__ src = reinterpret_cast<const F3*>(img) + ((size_t)b * h + y) * w;
+  const RunLists R = work.image(b, h);
+  const int slot0 = y * work.cap;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // `brk` = x + 1 of the last non-candidate pixel at or before a position (0: none yet in this row), so the
-  // run of a candidate pixel starts at the running maximum of brk
-  int carry = 0;
-  for (int x0 = 0; x0 < w; x0 += kChunk) {
-    const int xt = x0 + tid * kPxPerThread;
-    bool m[kPxPerThread];
-    int local = 0;
+  const unsigned long long below = (1ull << lane) - 1;
+  int runs_before = 0;  // runs that start left of this chunk
+  int chunk_edge = 0;   // candidate flag of the last pixel of the previous chunk
+  for (int x0 = 0; x0 <= w; x0 += kChunk) {
+    bool m[P];
+    int left[P];
 #pragma unroll
-    for (int k = 0; k < kPxPerThread; ++k) {
-      const int x = xt + k;
+    for (int k = 0; k < P; ++k) {
+      const int x = x0 + k * kRowThreads + tid;
       m[k] = x < w && is_candidate(src[x], lo, hi);
-      if (!m[k]) local = x + 1;
     }
-    // exclusive prefix of `local` over the threads of the chunk
-    const int incl = wave_scan_max(local);
-    if (lane == 63) wave_last[wave] = incl;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      left[k] = __shfl_up(m[k] ? 1 : 0, 1);
+      if (lane == 63) edge_of[k * NW + wave] = m[k] ? 1 : 0;
+    }
     __syncthreads();
-    int before = carry;
+    const int next_edge = edge_of[P * NW - 1];
+    unsigned long long start_mask[P];
 #pragma unroll
-    for (int k = 0; k < kRowThreads / 64; ++k)
-      if (k < wave) before = before > wave_last[k] ? before : wave_last[k];
-    int excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 0;
-    int run = before > excl ? before : excl;
+    for (int k = 0; k < P; ++k) {
+      if (lane == 0) left[k] = (k == 0 && wave == 0) ? chunk_edge : edge_of[k * NW + wave - 1];
+      start_mask[k] = __ballot(m[k] && !left[k]);
+      if (lane == 0) starts_of[k * NW + wave] = __popcll(start_mask[k]);
+    }
+    __syncthreads();
+    int before = runs_before;  // starts left of stripe k, wave `wave`
 #pragma unroll
-    for (int k = 0; k < kPxPerThread; ++k) {
-      const int x = xt + k;
-      if (x < w) {
-        if (m[k]) {
-          out[x] = base_label + run;
-        } else {
-          out[x] = -1;
-          run = x + 1;
+    for (int k = 0; k < P; ++k) {
+#pragma unroll
+      for (int v = 0; v < NW; ++v) {
+        const int n = starts_of[k * NW + v];
+        if (v == wave) {
+          // this thread's pixel of stripe k
+          const int x = x0 + k * kRowThreads + tid;
+          const int idx = before + __popcll(start_mask[k] & below);  // starts left of x
+          if (m[k] && !left[k]) {
+            const int slot = slot0 + idx;
+            R.span[2 * (size_t)slot] = (uint16_t)x;
+            R.parent[slot] = slot;
+            R.area[slot] = 0;
+          }
+          if (!m[k] && left[k]) R.span[2 * (size_t)(slot0 + idx - 1) + 1] = (uint16_t)(x - 1);
         }
+        before += n;
       }
     }
-    if (tid == kRowThreads - 1) carry_s = before > incl ? before : incl;
-    __syncthreads();
-    carry = carry_s;
+    runs_before = before;
+    chunk_edge = next_edge;
+    __syncthreads();  // the shared words are rewritten by the next chunk
   }
+  if (tid == 0) R.rowcount[y] = runs_before;
 }
 
 __device__ __forceinline__ int find_root(int32_t* parent, int a) {
@@ -125,116 +162,165 @@ __device__ __forceinline__ void unite(int32_t* parent, int a, int b) {
   }
 }
 
-// One thread per pixel.  A run pair is united at its first contact only (scanning left to right):
-//   upper pixel N is a candidate: first contact iff the left pixel or its upper pixel is not;
-//   otherwise NW counts iff the left pixel is not a candidate (else it already touched it as its N),
-//   and NE always counts (the right pixel would see it as its N only if N were a candidate too).
-__global__ __launch_bounds__(256) void mask_merge_kernel(int32_t* label, int h, int w) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  const int y = blockIdx.y;
-  if (x >= w || y == 0) return;
-  int32_t* L = label + (size_t)blockIdx.z * h * w;
-  const int i = y * w + x;
-  const int me = L[i];
-  if (me < 0) return;
-  const int up = i - w;
-  const int n = L[up];
-  const bool left = x > 0 && L[i - 1] >= 0;
-  if (n >= 0) {
-    const bool left_up = x > 0 && L[up - 1] >= 0;
-    if (!(left && left_up)) unite(L, me, n);
-  } else {
-    if (x > 0 && !left) {
-      const int nw = L[up - 1];
-      if (nw >= 0) unite(L, me, nw);
+// Workgroups walk rows; a thread takes a run, records its length as the area of its slot, and unites it
+// with every run of the row above whose columns meet [start - 1, end + 1].  Runs of a row are disjoint and
+// sorted, so their ends are sorted too: the first partner is found by bisection (in a copy of that row's list
+// in LDS when `stage` says it fits), the others follow it.
+__global__ __launch_bounds__(256) void mask_merge_kernel(const MaskWork work, int h, int stage) {
+  extern __shared__ uint32_t up_lds[];
+  const RunLists R = work.image(blockIdx.y, h);
+  const uint32_t* __restrict__ span = reinterpret_cast<const uint32_t*>(R.span);  // start | end << 16
+  for (int y = blockIdx.x; y < h; y += gridDim.x) {
+    const int n_cur = R.rowcount[y], n_up = y > 0 ? R.rowcount[y - 1] : 0;
+    if (n_cur == 0) continue;  // (uniform over the workgroup)
+    const int cur0 = y * work.cap, up0 = cur0 - work.cap;
+    const uint32_t* up = span + up0;
+    if (stage && n_up > 0) {
+      __syncthreads();  // the previous row's copy is no longer read
+      for (int j = threadIdx.x; j < n_up; j += 256) up_lds[j] = span[up0 + j];
+      __syncthreads();
+      up = up_lds;
     }
-    if (x + 1 < w) {
-      const int ne = L[up + 1];
-      if (ne >= 0) unite(L, me, ne);
+    for (int k = threadIdx.x; k < n_cur; k += 256) {
+      const uint32_t se = span[cur0 + k];
+      const int s = (int)(se & 0xFFFF) - 1, e = (int)(se >> 16) + 1;
+      R.area[cur0 + k] = e - s - 1;
+      int lo = 0, hi = n_up;  // first run above whose end is >= s
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)(up[mid] >> 16) < s) {
+          lo = mid + 1;
+        } else {
+          hi = mid;
+        }
+      }
+      for (int j = lo; j < n_up && (int)(up[j] & 0xFFFF) <= e; ++j) unite(R.parent, cur0 + k, up0 + j);
     }
   }
 }
 
-// One round of pointer jumping: label[i] <- its ancestor up to 8 levels up.  `flags[round]` is raised while
-// some label may still not be a root;
-// a round whose predecessor moved nothing returns at once (the launcher issues a fixed number of rounds, on
-// a fixed modest grid so that the idle ones cost microseconds).
-__global__ __launch_bounds__(256) void mask_flatten_kernel(int32_t* label, int n_px, int* flags, int round) {
-  if (round > 0 && flags[round - 1] == 0) return;
-  int32_t* L = label + (size_t)blockIdx.y * n_px;
+// One round of pointer jumping: parent[slot] <- its ancestor up to 8 levels up.  `flags[round]` is raised
+// while some run may still not point at a root; a round whose predecessor moved nothing returns at once (the
+// launcher issues a fixed number of rounds, on a fixed modest grid so that the idle ones cost microseconds).
+__global__ __launch_bounds__(256) void mask_flatten_kernel(const MaskWork work, int h, int round) {
+  if (round > 0 && work.flags[round - 1] == 0) return;
+  const RunLists R = work.image(blockIdx.y, h);
   bool moved = false;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_px; i += gridDim.x * 256) {
-    const int p = L[i];
-    if (p < 0) continue;
-    int a = p, g = L[a];
+  for (int y = blockIdx.x; y < h; y += gridDim.x) {
+    const int n = R.rowcount[y];
+    for (int k = threadIdx.x; k < n; k += 256) {
+      const int slot = y * work.cap + k;
+      const int p = R.parent[slot];
+      if (p == slot) continue;
+      int a = p, g = R.parent[a];
 #pragma unroll 1
-    for (int hop = 0; hop < 7 && g != a; ++hop) {  // up to 8 levels per round
-      a = g;
-      g = L[a];
-    }
-    if (g != p) {
-      L[i] = g;
-      if (L[g] != g) moved = true;  // not at a root yet (as far as this thread can see): another round
+      for (int hop = 0; hop < 7 && g != a; ++hop) {  // up to 8 levels per round
+        a = g;
+        g = R.parent[a];
+      }
+      if (g != p) {
+        R.parent[slot] = g;
+        if (R.parent[g] != g) moved = true;  // not at a root yet (as far as this thread can see): another round
+      }
     }
   }
-  if (moved) flags[round] = 1;
+  if (moved) work.flags[round] = 1;
 }
 
-constexpr int kAreaRun = 16;  // consecutive pixels per thread in mask_area_kernel (runs are horizontal)
-
-// area[root] += 1 for every candidate pixel.  A thread first folds its own 16 consecutive pixels (those that
-// share the root of its first candidate pixel), lanes with the same root then fold through the wave, and one
-// atomic goes out per distinct root; the few leftovers at component borders go out one by one.
-__global__ __launch_bounds__(256) void mask_area_kernel(const int32_t* __restrict__ label, int32_t* __restrict__ area,
-                                                        int n_px) {
-  const int32_t* __restrict__ L = label + (size_t)blockIdx.y * n_px;
-  int32_t* A = area + (size_t)blockIdx.y * n_px;
-  const int i0 = (blockIdx.x * 256 + threadIdx.x) * kAreaRun;
-  int r[kAreaRun];
+// area[root] += length of every run below it (every slot starts out with its own length).  A thread keeps the sum for the root it saw last and sends it when the
+// root changes; what is left at the end is folded over the lanes that share a root, one atomic per distinct
+// root: a component that covers half the image (a backdrop) would otherwise put every one of its runs on a
+// single address.
+__global__ __launch_bounds__(256) void mask_area_kernel(const MaskWork work, int h) {
+  const RunLists R = work.image(blockIdx.y, h);
+  int root = -1, sum = 0;
+  constexpr int U = 4;  // runs per thread in flight (the loads of one do not wait for those of another)
+  for (int y = blockIdx.x; y < h; y += gridDim.x) {
+    const int n = R.rowcount[y];
+    for (int k0 = threadIdx.x; k0 < n; k0 += 256 * U) {
+      int p[U], len[U];
 #pragma unroll
-  for (int k = 0; k < kAreaRun; ++k) r[k] = i0 + k < n_px ? L[i0 + k] : -1;
-  int first = -1;
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * 256, slot = y * work.cap + k;
+        p[u] = k < n ? R.parent[slot] : slot;
+      }
 #pragma unroll
-  for (int k = kAreaRun - 1; k >= 0; --k)
-    if (r[k] >= 0) first = r[k];
-  int mine = 0;
+      for (int u = 0; u < U; ++u) {
+        const int slot = y * work.cap + k0 + u * 256;
+        len[u] = p[u] != slot ? R.area[slot] : 0;  // a root: its own length is there already
+      }
 #pragma unroll
-  for (int k = 0; k < kAreaRun; ++k) {
-    if (r[k] == first) {
-      mine += 1;
-    } else if (r[k] >= 0) {
-      atomicAdd(&A[r[k]], 1);
+      for (int u = 0; u < U; ++u) {
+        const int slot = y * work.cap + k0 + u * 256;
+        if (p[u] == slot) continue;
+        if (p[u] == root) {
+          sum += len[u];
+        } else {
+          if (root >= 0) atomicAdd(&R.area[root], sum);
+          root = p[u];
+          sum = len[u];
+        }
+      }
     }
   }
-  // fold `mine` over the lanes that share `first`
-  bool pending = first >= 0;
+  bool pending = root >= 0;
   while (__any(pending)) {
     const unsigned long long todo = __ballot(pending);
     const int leader = __ffsll((long long)todo) - 1;
-    const int k = __shfl(first, leader);
-    const bool same = pending && first == k;
-    int sum = same ? mine : 0;
+    const int k = __shfl(root, leader);
+    const bool same = pending && root == k;
+    int total = same ? sum : 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&A[k], sum);
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&R.area[k], total);
     if (same) pending = false;
   }
 }
 
-// Fixed grid, grid-stride: a workgroup counts its hits locally and sends one atomic per image (one atomic
-// per wave would put hundreds of thousands of them on a single address).
-__global__ __launch_bounds__(256) void mask_apply_kernel(float* __restrict__ img, const int32_t* __restrict__ label,
-                                                         const int32_t* __restrict__ area, int n_px, int min_area,
-                                                         unsigned long long* __restrict__ count) {
+constexpr int kMaxWidth = 65535;                   // columns are stored in 16 bits
+constexpr int kBitmapWords = (kMaxWidth + 32) / 32;  // 8 KB of LDS
+
+// Workgroups walk rows.  Runs whose component is large enough set their columns in a bitmap of the row (whole
+// words by plain stores - no other run can own a bit of them - and the partial words at either end by
+// atomicOr); then every thread zeroes the pixels of its columns whose bit is set.  A workgroup counts what it
+// zeroes and sends one atomic per image at the end (one per row would put thousands on a single address).
+__global__ __launch_bounds__(256) void mask_apply_kernel(float* __restrict__ img, const MaskWork work, int h, int w,
+                                                         int min_area, unsigned long long* __restrict__ count) {
+  __shared__ uint32_t bitmap[kBitmapWords];
   __shared__ unsigned int wave_hits[4];
-  const size_t off = (size_t)blockIdx.y * n_px;
+  const RunLists R = work.image(blockIdx.y, h);
+  const uint32_t* __restrict__ span = reinterpret_cast<const uint32_t*>(R.span);
+  const int words = (w + 31) >> 5;
   unsigned int hits = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_px; i += gridDim.x * 256) {
-    const int root = label[off + i];
-    if (root >= 0 && area[off + root] >= min_area) {
-      reinterpret_cast<F3*>(img)[off + i] = F3{0.0f, 0.0f, 0.0f};
-      hits += 1;
+  for (int y = blockIdx.x; y < h; y += gridDim.x) {
+    const int n = R.rowcount[y];
+    if (n == 0) continue;  // (uniform over the workgroup)
+    for (int i = threadIdx.x; i < words; i += 256) bitmap[i] = 0;
+    __syncthreads();
+    bool any = false;
+    for (int k = threadIdx.x; k < n; k += 256) {
+      const int slot = y * work.cap + k;
+      if (R.area[R.parent[slot]] < min_area) continue;
+      const uint32_t se = span[slot];
+      const int s = (int)(se & 0xFFFF), e = (int)(se >> 16);
+      any = true;
+      hits += (unsigned)(e - s + 1);
+      const int ws = s >> 5, we = e >> 5;
+      const uint32_t first = 0xFFFFFFFFu << (s & 31), last = 0xFFFFFFFFu >> (31 - (e & 31));
+      if (ws == we) {
+        atomicOr(&bitmap[ws], first & last);
+      } else {
+        atomicOr(&bitmap[ws], first);
+        for (int i = ws + 1; i < we; ++i) bitmap[i] = 0xFFFFFFFFu;
+        atomicOr(&bitmap[we], last);
+      }
     }
+    if (__syncthreads_or(any ? 1 : 0)) {
+      F3* __restrict__ row = reinterpret_cast<F3*>(img) + ((size_t)blockIdx.y * h + y) * w;
+      for (int x = threadIdx.x; x < w; x += 256)
+        if ((bitmap[x >> 5] >> (x & 31)) & 1u) row[x] = F3{0.0f, 0.0f, 0.0f};
+    }
+    __syncthreads();  // the bitmap is cleared for the next row
   }
   if (!count) return;
 #pragma unroll
@@ -247,40 +333,70 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(float* __restrict__ img
   }
 }
 
-}  // namespace
-
-// rounds of pointer jumping issued: a round divides every label's distance to its root by 8, so a chain of
-// 2^31 nodes (more than an image with int32 labels can hold) is flat after 11 rounds; one more confirms it
+// rounds of pointer jumping issued: a round divides every run's distance to its root by 8, so a chain of
+// 2^31 nodes (more than an image with int32 slots can hold) is flat after 11 rounds; one more confirms it
 constexpr int kFlattenRounds = 12;
 
-size_t mask_workspace_bytes(int batch, int64_t n_px) {
-  return (size_t)batch * n_px * 2 * sizeof(int32_t) + (kFlattenRounds + 1) * sizeof(int);
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// byte offsets of the arrays inside the workspace
+struct MaskLayout {
+  size_t parent, area, rowcount, flags, total;  // (span sits at offset 0)
+};
+
+MaskLayout layout_of(int batch, int h, int w) {
+  const size_t slots = (size_t)h * ((w + 1) / 2);
+  MaskLayout l;
+  l.parent = align256((size_t)batch * slots * 2 * sizeof(uint16_t));
+  l.area = l.parent + align256((size_t)batch * slots * sizeof(int32_t));
+  l.rowcount = l.area + align256((size_t)batch * slots * sizeof(int32_t));
+  l.flags = l.rowcount + align256((size_t)batch * h * sizeof(int32_t));
+  l.total = l.flags + align256((kFlattenRounds + 1) * sizeof(int));
+  return l;
 }
+
+MaskWork carve(void* workspace, int batch, int h, int w) {
+  const MaskLayout l = layout_of(batch, h, w);
+  char* p = reinterpret_cast<char*>(workspace);
+  MaskWork m;
+  m.cap = (w + 1) / 2;
+  m.slots = (size_t)h * m.cap;
+  m.span = reinterpret_cast<uint16_t*>(p);
+  m.parent = reinterpret_cast<int32_t*>(p + l.parent);
+  m.area = reinterpret_cast<int32_t*>(p + l.area);
+  m.rowcount = reinterpret_cast<int32_t*>(p + l.rowcount);
+  m.flags = reinterpret_cast<int*>(p + l.flags);
+  return m;
+}
+
+}  // namespace
+
+size_t mask_workspace_bytes(int batch, int h, int w) { return layout_of(batch, h, w).total; }
 
 hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shadow_limit, double highlight_limit,
                                int min_area, void* workspace, unsigned long long* count_dev, hipStream_t st) {
-  const int64_t n_px = (int64_t)h * w;
-  if (h < 1 || w < 1 || batch < 1 || batch > 65535 || h > 65535 || n_px > INT32_MAX) return hipErrorInvalidValue;
-  int32_t* label = reinterpret_cast<int32_t*>(workspace);
-  int32_t* area = label + (size_t)batch * n_px;
-  int* flags = reinterpret_cast<int*>(area + (size_t)batch * n_px);
-  hipError_t e = hipMemsetAsync(area, 0, (size_t)batch * n_px * sizeof(int32_t) + (kFlattenRounds + 1) * sizeof(int), st);
+  if (h < 1 || w < 1 || w > kMaxWidth || batch < 1 || batch > 65535 || (int64_t)h * ((w + 1) / 2) > INT32_MAX)
+    return hipErrorInvalidValue;
+  const MaskWork work = carve(workspace, batch, h, w);
+  hipError_t e = hipMemsetAsync(work.flags, 0, (kFlattenRounds + 1) * sizeof(int), st);
   if (e != hipSuccess) return e;
   if (count_dev) {
     e = hipMemsetAsync(count_dev, 0, (size_t)batch * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(mask_runs_kernel, dim3(h, batch), dim3(kRowThreads), 0, st, img, label, h, w, shadow_limit,
+  // (rows go to the x dimension of the grid, which has no 65535 limit)
+  hipLaunchKernelGGL(mask_runs_kernel, dim3(h, batch), dim3(kRowThreads), 0, st, img, work, h, w, shadow_limit,
                      highlight_limit);
-  hipLaunchKernelGGL(mask_merge_kernel, dim3((w + 255) / 256, h, batch), dim3(256), 0, st, label, h, w);
-  const unsigned blocks = (unsigned)((n_px + 255) / 256);
-  const unsigned flat_blocks = blocks < 4096 ? blocks : 4096;
+  const unsigned row_blocks = (unsigned)(h < 2048 ? h : 2048);
+  const size_t up_bytes = (size_t)work.cap * sizeof(uint32_t);
+  const int stage = up_bytes <= 48 * 1024;
+  hipLaunchKernelGGL(mask_merge_kernel, dim3(row_blocks, batch), dim3(256), stage ? up_bytes : 0, st, work, h, stage);
   for (int round = 0; round < kFlattenRounds; ++round)
-    hipLaunchKernelGGL(mask_flatten_kernel, dim3(flat_blocks, batch), dim3(256), 0, st, label, (int)n_px, flags, round);
-  const unsigned area_blocks = (unsigned)((n_px + 256 * kAreaRun - 1) / (256 * kAreaRun));
-  hipLaunchKernelGGL(mask_area_kernel, dim3(area_blocks, batch), dim3(256), 0, st, label, area, (int)n_px);
-  hipLaunchKernelGGL(mask_apply_kernel, dim3(flat_blocks, batch), dim3(256), 0, st, img, label, area, (int)n_px,
-                     min_area, count_dev);
+    hipLaunchKernelGGL(mask_flatten_kernel, dim3(row_blocks, batch), dim3(256), 0, st, work, h, round);
+  const unsigned area_blocks = (unsigned)(h < 256 ? h : 256);
+  hipLaunchKernelGGL(mask_area_kernel, dim3(area_blocks, batch), dim3(256), 0, st, work, h);
+  hipLaunchKernelGGL(mask_apply_kernel, dim3(row_blocks, batch), dim3(256), 0, st, img, work, h, w, min_area,
+                     count_dev);
   return hipGetLastError();
 }
 

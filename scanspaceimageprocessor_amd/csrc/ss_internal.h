@@ -42,8 +42,9 @@ hipError_t launch_exposure_multipliers(const float* brightness, int n, int ref_i
 constexpr int kLabDetectBlocks = 1024;
 // ---- mask.hip ----------------------------------------------------------------------------------
 // _apply_masking: candidates by luminance, 8-connected components, components >= min_area zeroed in place.
-// workspace: mask_workspace_bytes(batch, n_px) bytes of device memory; count_dev: optional [batch] counters.
-size_t mask_workspace_bytes(int batch, int64_t n_px);
+// workspace: mask_workspace_bytes(batch, h, w) bytes of device memory (about 6 bytes per pixel: the run lists
+// are sized for the worst case); count_dev: optional [batch] counters.  w <= 65535.
+size_t mask_workspace_bytes(int batch, int h, int w);
 hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shadow_limit, double highlight_limit,
                                int min_area, void* workspace, unsigned long long* count_dev, hipStream_t st);
 

@@ -88,6 +88,50 @@ def test_long_thin_structures():
     check(from_mask(anti))
 
 
+@pytest.mark.parametrize("w", [1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4100])
+def test_row_widths_around_the_scan_boundaries(w):
+    # runs that start, end or continue across lane / wave / stripe / chunk boundaries of the row scan, and
+    # runs touching either border
+    rng = np.random.default_rng(w)
+    h = 9
+    mask = rng.random((h, w)) < 0.55
+    mask[0, :] = True                      # one run as long as the row
+    mask[1, :] = False
+    mask[2, ::2] = True                    # the most runs a row can hold, starting at column 0 ...
+    mask[2, 1::2] = False
+    mask[3, ::2] = False                   # ... and at column 1: a checkerboard pair, 8-connected
+    mask[3, 1::2] = True
+    mask[4, :] = False
+    mask[5, -1] = True
+    mask[6, 0] = True
+    check(from_mask(mask, seed=1), min_area=3)
+    check(from_mask(mask, seed=1), min_area=1)
+
+
+def test_checkerboard_is_one_component():
+    h, w = 64, 301
+    yy, xx = np.indices((h, w))
+    check(from_mask((yy + xx) % 2 == 0), min_area=h * w // 2)
+    check(from_mask((yy + xx) % 2 == 0), min_area=h * w // 2 + 2)   # one more than it has: nothing is masked
+
+
+def test_single_row_and_single_column():
+    rng = np.random.default_rng(11)
+    check(from_mask(rng.random((1, 3000)) < 0.7), min_area=4)
+    check(from_mask(rng.random((3000, 1)) < 0.7), min_area=4)
+    check(from_mask(np.ones((1, 1), bool)), min_area=1)
+
+
+def test_wide_rows_with_many_runs():
+    rng = np.random.default_rng(12)
+    check(from_mask(rng.random((40, 5000)) < 0.45, seed=2), min_area=30)
+    # vertical stripes joined along the bottom row: every row holds w / 3 runs of one component
+    mask = np.zeros((50, 4500), bool)
+    mask[:, ::3] = True
+    mask[-1, :] = True
+    check(from_mask(mask), min_area=1000)
+
+
 def test_area_threshold_and_limits_are_inclusive():
     mask = np.zeros((60, 60), bool)
     mask[2:12, 3:23] = True    # exactly 200
