@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
   // Chains with the shadows/highlights stage use more scalars than the register file holds.  They read the
   // parameter block through a pointer to the kernel argument segment the compiler cannot see through, once
   // per trip: scalar loads next to the uses instead of scalars parked in (and fetched back from) vector lanes.
+  // (The parameter block is the kernel's first argument: offset 0 of the argument segment.)
   auto params_now = [&]() -> const ChainParams& {
     if constexpr (SH && !ccm_needs_table<CCMC>) {  // (no gain measured for the table-driven corrections)
       typedef const __attribute__((address_space(4))) ChainParams* KernargParams;

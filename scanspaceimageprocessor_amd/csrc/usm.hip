@@ -160,7 +160,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   };
   // The parameter block as the kernel argument segment holds it, behind a pointer the compiler cannot see
   // through: scalars read through it are loaded (scalar loads) in the phase that uses them instead of all
-  // living in scalar registers, spilled to vector lanes, across the whole walk.
+  // living in scalar registers, spilled to vector lanes, across the whole walk.  (The parameter block is the
+  // kernel's first argument: offset 0 of the argument segment.)
   auto params_now = [&]() -> const ChainParams& {
     if constexpr (!PLAIN) {  // (the plain chain uses few enough parameters to keep them)
       typedef const __attribute__((address_space(4))) ChainParams* KernargParams;
