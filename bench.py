@@ -54,8 +54,10 @@ def synthetic_swatches():
 
 
 def cpu_baseline(amount, n_images=3):
-    """Time the numpy restatement of the reference path on a bounded sample of the workload, single-threaded:
-    `n_images` of the 64 images (about 4.5 s each), generated outside the timed region."""
+    """Time the numpy restatement of the reference path on a bounded sample of the workload: `n_images` of the
+    64 images single-threaded (about 4.5 s each on the GPU box's host; this is the reported baseline), then
+    one image on each of 4 threads, the reference's default worker count (`threads4`).  Inputs are generated
+    outside the timed regions."""
     from oracle import chain as oc
     from oracle import inputs
 
@@ -77,10 +79,31 @@ def cpu_baseline(amount, n_images=3):
     else:
         run_all()
     dt = time.perf_counter() - t0
+    # the reference's own default: 4 worker threads (image_space.py:238), one image each
+    threads = 4
+    from concurrent.futures import ThreadPoolExecutor
+
+    more = imgs + [inputs.linear_image(1234 + n_images, H, W)] if n_images < threads else imgs
+    more = more[:threads]
+
+    def run_threads():
+        with ThreadPoolExecutor(threads) as pool:
+            list(pool.map(lambda im: oc.config2(im, M_T, M_R, 1.1, amount, 2.0, 0.0), more))
+
+    t1 = time.perf_counter()
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            run_threads()
+    else:
+        run_threads()
+    dt_mt = time.perf_counter() - t1
     return {
         "value": round(n_images * H * W / 1e6 / dt, 3), "unit": "MP/s", "cores": 1, "kind": "port",
         "sample": f"{n_images} of the 64 images of {H}x{W} (24 MP) through oracle.chain.config2 (float64 numpy restatement "
                   f"of the reference CPU path, BLAS limited to 1 thread), {dt:.1f} s; host has {os.cpu_count()} logical CPUs",
+        "threads4": {"value": round(len(more) * H * W / 1e6 / dt_mt, 3), "unit": "MP/s", "cores": threads,
+                     "sample": f"{len(more)} images on {threads} Python threads (the reference's default worker count), "
+                               f"{dt_mt:.1f} s"},
     }
 
 
