@@ -205,10 +205,8 @@ size_t out_bytes_per_px(int out_kind) {
 
 int ensure_pinned(ss_ctx* c) {
   for (int i = 0; i < 2; ++i) {
-    if (!c->pinned[i]) {
-      SS_HIP(c, hipHostMalloc(&c->pinned[i], kStageBytes, hipHostMallocDefault));
-      SS_HIP(c, hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming));
-    }
+    if (!c->pinned[i]) SS_HIP(c, hipHostMalloc(&c->pinned[i], kStageBytes, hipHostMallocDefault));
+    if (!c->pinned_free[i]) SS_HIP(c, hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming));
   }
   return SS_OK;
 }
@@ -380,8 +378,10 @@ int ss_ctx_create(int device, ss_ctx** out_ctx) {
     delete c;
     return fail(nullptr, SS_ERR_NOMEM, "hipMalloc of the work-queue counter failed: %s", hipGetErrorString(e));
   }
-  hipEventCreate(&c->t0);
-  hipEventCreate(&c->t1);
+  if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+    ss_ctx_destroy(c);
+    return fail(nullptr, SS_ERR_HIP, "hipEventCreate failed");
+  }
   *out_ctx = c;
   return SS_OK;
 }
