@@ -217,6 +217,14 @@ int ss_exposure_stats(ss_ctx* ctx, const float* thumbs_dev, int32_t height, int3
 int ss_exposure_multipliers(ss_ctx* ctx, const float* brightness_dev, int32_t n, int32_t ref_index,
                             int32_t first, int32_t count, float* mult_dev);
 
+/* ---- 16-bit RAW decode output -> float32 ------------------------------------------------------ */
+
+/* load_image's `np.array(rgb, dtype=np.float32) / 65535.0` (imageProcessorWorker.py:313; imageLoader.py:92) on
+ * the device, so that the 16-bit output of the RAW decoder can be uploaded as it is (half the bytes of the float
+ * image, and no float conversion pass on the host): dst[i] = float(src[i]) / 65535.0f, IEEE division, bit for
+ * bit numpy's result.  n_values = height * width * 3 of a batch; both pointers 16-byte aligned.  Asynchronous. */
+int ss_unpack_u16(ss_ctx* ctx, const uint16_t* src_dev, float* dst_dev, uint64_t n_values);
+
 /* ---- LAB-input heuristic ------------------------------------------------------------------ */
 
 /* _is_lab_image (editingTools.py:411-432): max(ch0) > 1.5 and (min(ch1) < -1 or min(ch2) < -1).

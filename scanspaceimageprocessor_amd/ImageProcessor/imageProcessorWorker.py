@@ -141,6 +141,8 @@ class ImageCorrectionWorker:
         """RAW -> float32 linear sRGB in [0,1] on the host (rawpy/LibRaw), then the optional
         negative inversion (reference imageProcessorWorker.py:291-325)."""
         raw_img_float = self._decode_raw(img_path)
+        if raw_img_float.dtype == np.uint16:
+            raw_img_float = np.array(raw_img_float, dtype=np.float32) / np.float32(65535.0)
         return ensure_positive_if_negative(raw_img_float, enabled=self.negative_mode,
                                            low_percentile=self.negative_low_pct,
                                            high_percentile=self.negative_high_pct)
@@ -240,22 +242,30 @@ class ImageCorrectionWorker:
     def process_array(self, raw_img_float: np.ndarray, img_path: str = ""):
         """Steps 5-7 of the reference's ``run`` on one decoded image, resident on the GPU:
         returns ``(encoded, preview_uint8)``.  ``raw_img_float`` is the output of the RAW decode
-        BEFORE negative inversion (the inversion runs on the device here)."""
+        BEFORE negative inversion (the inversion runs on the device here).  A uint16 array is taken as the
+        RAW decoder's 16-bit output: it is uploaded as it is and divided by 65535 on the device (the
+        reference's ``np.array(rgb, dtype=np.float32) / 65535.0``, imageProcessorWorker.py:313)."""
         ctx = default_context()
-        img = np.ascontiguousarray(raw_img_float, dtype=np.float32)
+        raw16 = isinstance(raw_img_float, np.ndarray) and raw_img_float.dtype == np.uint16
+        img = np.ascontiguousarray(raw_img_float, dtype=np.uint16 if raw16 else np.float32)
         h, w, _ = img.shape
         kind = self._out_kind(self.output_format)
         kw = self.chain_stages(img_path)
         # buffers stay with the thread's context from image to image
-        src = ctx.workspace("worker.src", img.nbytes)
-        dst = ctx.workspace("worker.dst", img.nbytes)
+        f32_bytes = h * w * 3 * 4
+        src = ctx.workspace("worker.src", f32_bytes)
+        dst = ctx.workspace("worker.dst", f32_bytes)
         neg = ctx.workspace("worker.neg", _lib.SS_NEG_PARAM_STRIDE * 4) if self.negative_mode else None
-        ctx.upload(src, img)
+        if raw16:
+            ctx.upload(dst, img)                       # staged in the output buffer, which is free until the chain runs
+            ctx.unpack_u16(dst, src, h * w * 3)
+        else:
+            ctx.upload(src, img)
         if self.negative_mode:
             ctx.negative_params(src, h, w, 1, self.negative_low_pct, self.negative_high_pct,
                                 editingTools.NUMPY_LEGACY_PERCENTILE, neg)
             kw.update(neg=True, neg_params_dev=neg)
-        encoded = np.empty(img.shape, dtype=_lib.OUT_DTYPES[kind])
+        encoded = np.empty((h, w, 3), dtype=_lib.OUT_DTYPES[kind])
         if getattr(self, "export_masked", False):
             # reference order (imageProcessorWorker.py:902-912): chain -> _apply_masking -> encode.  The chain
             # leaves the clipped linear image in `dst`, the masking zeroes regions in place, and the encode
@@ -267,7 +277,7 @@ class ImageCorrectionWorker:
             if encoded.dtype == np.uint8:
                 preview = encoded
             else:
-                preview = np.empty(img.shape, dtype=np.uint8)
+                preview = np.empty((h, w, 3), dtype=np.uint8)
                 ctx.chain_run(make_desc(h, w, 1, out="u8_linear"), dst, src)
                 ctx.download(preview, src)
             return encoded, preview
@@ -317,15 +327,18 @@ class ImageCorrectionWorker:
     # ------------------------------------------------------------------ host I/O hooks
 
     def _decode_raw(self, img_path: str) -> np.ndarray:
+        """The RAW decode of ``load_image`` (imageProcessorWorker.py:304-313).  Returns the decoder's uint16 image
+        (``process_array`` divides by 65535 on the device); a ``raw_loader`` hook may return uint16 or float data."""
         if self.raw_loader is not None:
-            return np.asarray(self.raw_loader(img_path), dtype=np.float32)
+            arr = np.asarray(self.raw_loader(img_path))
+            return arr if arr.dtype == np.uint16 else np.asarray(arr, dtype=np.float32)
         self.signals.log.emit(f"[RAW] Using original path for rawpy: {img_path}")
         import rawpy  # host decode stays on LibRaw
 
         with rawpy.imread(img_path) as raw:
             rgb = raw.postprocess(output_bps=16, gamma=(1, 1), no_auto_bright=True, use_camera_wb=True,
                                   output_color=rawpy.ColorSpace.sRGB)
-            return np.array(rgb, dtype=np.float32) / 65535.0
+            return np.ascontiguousarray(rgb, dtype=np.uint16)
 
     def _write(self, out_path: str, encoded: np.ndarray, ext: str) -> None:
         if self.image_writer is not None:

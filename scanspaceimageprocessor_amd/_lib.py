@@ -102,6 +102,7 @@ SIGNATURES = {
                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "ss_exposure_multipliers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p]),
+    "ss_unpack_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ss_is_lab_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ss_mask_regions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                   C.c_int32, C.c_void_p]),
@@ -246,6 +247,10 @@ class Context:
         self.check(self.lib.ss_exposure_multipliers(self.handle, C.c_void_p(brightness_dev), n,
                                                     -1 if ref_index is None else int(ref_index),
                                                     first, count, C.c_void_p(mult_dev)))
+
+    def unpack_u16(self, src_dev, dst_dev, n_values):
+        """float32(src) / 65535 on the device: the RAW decoder's 16-bit output to the chain's input (asynchronous)."""
+        self.check(self.lib.ss_unpack_u16(self.handle, C.c_void_p(src_dev), C.c_void_p(dst_dev), int(n_values)))
 
     def is_lab_image(self, src_dev, n_pixels, out_dev, minmax_dev=None):
         self.check(self.lib.ss_is_lab_image(self.handle, C.c_void_p(src_dev), int(n_pixels),

@@ -546,6 +546,18 @@ int ss_is_lab_image(ss_ctx* c, const float* src_dev, int64_t n_pixels, int32_t* 
   return SS_OK;
 }
 
+int ss_unpack_u16(ss_ctx* c, const uint16_t* src_dev, float* dst_dev, uint64_t n_values) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!src_dev || !dst_dev) return fail(c, SS_ERR_INVALID, "src_dev and dst_dev must not be NULL");
+  if (((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15)
+    return fail(c, SS_ERR_INVALID, "src_dev and dst_dev must be 16-byte aligned");
+  if (n_values == 0) return SS_OK;
+  hipError_t e = launch_unpack_u16(src_dev, dst_dev, n_values, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "unpack kernel failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
 int ss_mask_regions(ss_ctx* c, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
                     double highlight_limit, int32_t min_area, uint64_t* masked_count_dev) {
   int rc = check_ctx(c);

@@ -124,6 +124,41 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16-bit RAW output -> float32 (imageProcessorWorker.py:313: np.array(rgb, dtype=np.float32) / 65535.0)
+// ------------------------------------------------------------------------------------------------
+
+// One lane converts 8 values: a 16-byte load, two 16-byte stores.  The division is IEEE float32 division,
+// as numpy's is (a multiplication by the reciprocal differs in the last bit for some inputs).
+__global__ __launch_bounds__(256) void unpack_u16_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst,
+                                                         uint64_t n) {
+  const uint64_t n8 = n / 8;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = __fdiv_rn((float)(w[k] & 0xFFFFu), 65535.0f);
+      f[2 * k + 1] = __fdiv_rn((float)(w[k] >> 16), 65535.0f);
+    }
+    reinterpret_cast<float4*>(dst)[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
+    reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+  }
+  if (blockIdx.x == 0) {
+    const uint64_t i = n8 * 8 + threadIdx.x;
+    if (i < n) dst[i] = __fdiv_rn((float)src[i], 65535.0f);
+  }
+}
+
+hipError_t launch_unpack_u16(const uint16_t* src, float* dst, uint64_t n, hipStream_t st) {
+  uint64_t blocks = (n / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(unpack_u16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
+  return hipGetLastError();
+}
+
 template <int CCMC, bool SH>
 static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
                                    hipStream_t st) {

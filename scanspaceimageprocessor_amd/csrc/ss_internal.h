@@ -48,6 +48,9 @@ size_t mask_workspace_bytes(int batch, int h, int w);
 hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shadow_limit, double highlight_limit,
                                int min_area, void* workspace, unsigned long long* count_dev, hipStream_t st);
 
+// uint16 -> float32 / 65535 (chain.hip); src 16-byte aligned, dst 16-byte aligned
+hipError_t launch_unpack_u16(const uint16_t* src, float* dst, uint64_t n, hipStream_t st);
+
 // area-average downscale (resize.hip); dh <= sh, dw <= sw
 hipError_t launch_resize_area(const float* src, int sh, int sw, int batch, float* dst, int dh, int dw, hipStream_t st);
 

@@ -114,3 +114,41 @@ def test_run_writes_files_with_the_built_in_containers(tmp_path):
                 got = np.asarray(im)
         assert got.dtype == want.dtype
         assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int64))) <= 1
+
+
+def test_unpack_u16_is_numpys_division_bit_for_bit():
+    from gpu_util import DeviceBuffer
+    from scanspaceimageprocessor_amd import default_context
+
+    ctx = default_context()
+    for n in (65536, 65536 + 13, 5):
+        vals = np.arange(n, dtype=np.uint64).astype(np.uint16) if n >= 65536 else np.array([0, 1, 65535, 32768, 7], np.uint16)
+        src = DeviceBuffer.from_array(ctx, vals)
+        dst = DeviceBuffer(ctx, 4 * n)
+        try:
+            ctx.unpack_u16(src.ptr, dst.ptr, n)
+            ctx.sync()
+            got = dst.to_array((n,), np.float32)
+        finally:
+            src.free(); dst.free()
+        want = np.array(vals, dtype=np.float32) / 65535.0   # imageProcessorWorker.py:313
+        assert want.dtype == np.float32
+        np.testing.assert_array_equal(got, want)
+
+
+def test_worker_takes_the_decoders_uint16_output():
+    from oracle import inputs
+    from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as ipw
+
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    rng = np.random.default_rng(5)
+    raw16 = (rng.random((96, 130, 3)) ** 2.2 * 60000).astype(np.uint16)
+    as_float = np.array(raw16, dtype=np.float32) / 65535.0
+    for fmt, depth in ((".tiff", 16), (".jpg", 8)):
+        w = ipw.ImageCorrectionWorker(["a.nef"], M_T, "/tmp", None, output_format=fmt, tiff_bitdepth=depth,
+                                      sharpen_amount=40.0)
+        e16, p16 = w.process_array(raw16, "a.nef")
+        ef, pf = w.process_array(as_float, "a.nef")
+        np.testing.assert_array_equal(e16, ef)
+        np.testing.assert_array_equal(p16, pf)

@@ -42,8 +42,48 @@ from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as i
 M_R = 0.03 + 0.87 * np.random.default_rng(7).random((24, 3))
 M_T = (M_R @ (np.eye(3) * 0.95 + 0.02).T).astype(np.float32)
 ipw.set_reference_swatches(M_R)
+raw16 = (img * 65535.0).astype(np.uint16)
+timeit("host: np.array(rgb, dtype=np.float32) / 65535.0 (the reference's conversion)", lambda: np.array(raw16, dtype=np.float32) / 65535.0)
 for fmt, depth, masked in ((".tiff", 16, False), (".jpg", 8, False), (".tiff", 16, True)):
     w = ipw.ImageCorrectionWorker(["a.nef"], M_T, "/tmp", None, output_format=fmt, tiff_bitdepth=depth, shadow_adj=10.0,
                                   export_masked=masked)
     timeit(f"worker.process_array chart mode -> {fmt} {depth}-bit{' masked' if masked else ''} (+ 8-bit preview)",
            lambda: w.process_array(img, "a.nef"))
+    if not masked:
+        timeit(f"  the same from the decoder's uint16 image", lambda: w.process_array(raw16, "a.nef"))
+
+# The reference runs several images at once, one worker thread each (4 by default, image_space.py:238): one context
+# (own stream, own staging buffers) per thread, so one thread's upload overlaps another's download and kernels.
+import threading
+
+from scanspaceimageprocessor_amd import Context
+
+
+def threads_run(n_threads, per_thread=6):
+    ctxs = [Context(0) for _ in range(n_threads)]
+    for c in ctxs:
+        c.chain_run_host(d16, img)  # warm-up: staging buffers, workspaces
+    barrier = threading.Barrier(n_threads + 1)
+
+    def work(c):
+        barrier.wait()
+        for _ in range(per_thread):
+            c.chain_run_host(d16, img)
+
+    ts = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+    for t in ts:
+        t.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    n = n_threads * per_thread
+    print(f"{n_threads} worker threads x {per_thread} images, ss_chain_run_host -> u16: {dt / n * 1e3:8.1f} ms per image  "
+          f"{n * H * W / 1e6 / dt:8.0f} MP/s aggregate", flush=True)
+
+
+for n_threads in (1, 2, 4, 8):
+    threads_run(n_threads)
