@@ -8,7 +8,9 @@ The reference shrinks decoded images with ``cv2.resize(..., interpolation=cv2.IN
 * ``MainWindow._resize_for_preview`` (image_space.py:2959-2986): the edit preview, at most 4 MP.
 
 The functions below keep those size rules and hand the resampling to ``ss_resize_area``.  RAW decoding itself
-(rawpy) is not part of this package: callers pass the decoded float32 array.
+(rawpy) is not part of this package: callers pass the decoded image, either as the float32 array the reference
+forms (``rgb.astype(np.float32) / 65535.0``, imageLoader.py:92) or as the decoder's uint16 array itself, which is
+then uploaded as it is (half the bytes) and divided by 65535 on the device, with the same result.
 """
 
 from __future__ import annotations
@@ -59,11 +61,37 @@ def resize_area(arr, dsize, ctx=None):
     return ctx.resize_area_host(arr, new_w, new_h)
 
 
+def _to_float(arr16):
+    return np.array(arr16, dtype=np.float32) / np.float32(65535.0)  # imageLoader.py:92
+
+
+def _resize_area_u16(arr16, dsize, ctx=None):
+    """``resize_area(float32(arr16) / 65535, dsize)`` with the conversion on the device."""
+    new_w, new_h = int(dsize[0]), int(dsize[1])
+    if new_w < 1 or new_h < 1:
+        raise ValueError(f"Invalid image dimensions: {new_w}x{new_h}")
+    ctx = ctx or default_context()
+    arr16 = np.ascontiguousarray(arr16)
+    h, w, _ = arr16.shape
+    raw = ctx.workspace("loader.raw16", arr16.nbytes)
+    full = ctx.workspace("loader.f32", arr16.size * 4)
+    small = ctx.workspace("loader.small", new_h * new_w * 12)
+    ctx.upload(raw, arr16)
+    ctx.unpack_u16(raw, full, arr16.size)
+    ctx.resize_area(full, h, w, 1, small, new_h, new_w)
+    out = np.empty((new_h, new_w, 3), dtype=np.float32)
+    ctx.download(out, small)
+    return out
+
+
 def raw_preview(full_fp, target_pixels=RAW_PREVIEW_PIXELS, ctx=None):
-    """``RawLoadWorker.run`` after the decode (imageLoader.py:91-124): float32 in, shrunk to ``target_pixels``
-    when larger, NaN / infinity rejected (imageLoader.py:117-118)."""
-    full_fp = _check_image(full_fp).astype(np.float32, copy=False)
+    """``RawLoadWorker.run`` after the decode (imageLoader.py:91-124): float32 (or the decoder's uint16) in,
+    shrunk to ``target_pixels`` when larger, NaN / infinity rejected (imageLoader.py:117-118)."""
+    full_fp = _check_image(full_fp)
     size = preview_size(full_fp.shape[0], full_fp.shape[1], target_pixels)
+    if full_fp.dtype == np.uint16:
+        return _to_float(full_fp) if size is None else _resize_area_u16(full_fp, size, ctx)
+    full_fp = full_fp.astype(np.float32, copy=False)
     if size is None:
         return full_fp
     if not np.isfinite(full_fp).all():
@@ -73,8 +101,11 @@ def raw_preview(full_fp, target_pixels=RAW_PREVIEW_PIXELS, ctx=None):
 
 def thumbnail_from_array(arr, max_size=(512, 512), ctx=None):
     """The fallback branch of ``load_thumbnail_array_from_raw`` after the decode (imageLoader.py:296-306)."""
-    arr = _check_image(arr).astype(np.float32, copy=False)
+    arr = _check_image(arr)
     size = thumbnail_size(arr.shape[0], arr.shape[1], max_size)
+    if arr.dtype == np.uint16:
+        return _to_float(arr) if size is None else _resize_area_u16(arr, size, ctx)
+    arr = arr.astype(np.float32, copy=False)
     if size is None:
         return arr
     return resize_area(arr, size, ctx)

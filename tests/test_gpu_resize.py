@@ -76,3 +76,14 @@ def test_small_images_pass_through_and_bad_input_is_rejected():
         il.raw_preview(big)
     with pytest.raises(RuntimeError):
         il.resize_area(img, (200, 50))  # wider than the source: the library only shrinks
+
+
+def test_uint16_decoder_output_gives_the_same_previews():
+    rng = np.random.default_rng(21)
+    raw16 = (rng.random((1300, 1900, 3)) ** 2.2 * 65535).astype(np.uint16)
+    as_float = np.array(raw16, dtype=np.float32) / 65535.0   # imageLoader.py:92
+    np.testing.assert_array_equal(il.raw_preview(raw16), il.raw_preview(as_float))
+    np.testing.assert_array_equal(il.thumbnail_from_array(raw16), il.thumbnail_from_array(as_float))
+    small16 = raw16[:100, :150]
+    np.testing.assert_array_equal(il.raw_preview(small16), as_float[:100, :150])
+    np.testing.assert_array_equal(il.thumbnail_from_array(small16), as_float[:100, :150])
