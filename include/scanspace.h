@@ -264,7 +264,14 @@ int ss_mask_regions(ss_ctx* ctx, float* img_dev, int32_t height, int32_t width, 
 
 int ss_malloc(ss_ctx* ctx, uint64_t bytes, void** out_dev);
 int ss_free(ss_ctx* ctx, void* dev);
-/* Synchronous copies through the context's pinned staging ring. */
+/* Page-locked host memory.  The reference hands numpy arrays in pageable memory across its call boundary
+ * (imageProcessorWorker.py:313, 337), which every host entry point here accepts and stages through the
+ * context's pinned ring; buffers from ss_host_alloc (or any other page-locked memory: hipHostMalloc,
+ * hipHostRegister, a pinned torch tensor) are recognised and copied by the DMA engines directly, without the
+ * staging copy. */
+int ss_host_alloc(ss_ctx* ctx, uint64_t bytes, void** out_host);
+int ss_host_free(ss_ctx* ctx, void* host); /* ctx may be NULL when the context is already destroyed */
+/* Synchronous copies (through the context's pinned staging ring unless the host side is page-locked). */
 int ss_upload(ss_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int ss_download(ss_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 

@@ -111,6 +111,8 @@ SIGNATURES = {
     "ss_resize_area_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "ss_malloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "ss_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_host_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ss_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ss_timer_start": (C.c_int, [C.c_void_p]),
@@ -221,6 +223,27 @@ class Context:
         ws[tag] = (ptr, int(nbytes))
         return ptr
 
+    def pinned_empty(self, shape, dtype=np.float32):
+        """An uninitialised numpy array in page-locked host memory: uploads from it and downloads into it skip the
+        staging copy.  The memory is released when the array (and every view of it) is gone."""
+        import weakref
+
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes <= 0:
+            return np.empty(shape, dtype=dtype)
+        ptr = C.c_void_p()
+        self.check(self.lib.ss_host_alloc(self.handle, nbytes, C.byref(ptr)))
+        buf = (C.c_ubyte * nbytes).from_address(ptr.value)
+        lib, address, owner = self.lib, ptr.value, weakref.ref(self)
+
+        def release():
+            ctx = owner()
+            lib.ss_host_free(ctx.handle if ctx is not None and ctx.handle else None, C.c_void_p(address))
+
+        weakref.finalize(buf, release)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
     def upload(self, dst_dev, arr):
         arr = np.ascontiguousarray(arr)
         self.check(self.lib.ss_upload(self.handle, C.c_void_p(dst_dev), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
@@ -279,11 +302,16 @@ class Context:
         return out
 
     # -- entry point on host arrays
-    def chain_run_host(self, desc, src, neg_auto=False, low=0.05, high=0.995, legacy_numpy=True, lab_auto=False):
+    def chain_run_host(self, desc, src, neg_auto=False, low=0.05, high=0.995, legacy_numpy=True, lab_auto=False,
+                       out=None):
         """Run the chain on a C-contiguous float32 array of shape (H, W, 3) or (B, H, W, 3).
-        Returns ``(out, lab_detected)``."""
+        Returns ``(out, lab_detected)``; ``out`` may be supplied (e.g. from ``pinned_empty``)."""
         src = np.ascontiguousarray(src, dtype=np.float32)
-        out = np.empty(src.shape, dtype=OUT_DTYPES[desc.out_kind])
+        if out is None:
+            out = np.empty(src.shape, dtype=OUT_DTYPES[desc.out_kind])
+        elif (out.shape != src.shape or out.dtype != OUT_DTYPES[desc.out_kind] or not out.flags.c_contiguous
+              or not out.flags.writeable):
+            raise ValueError("out must be a writeable C-contiguous array of the input's shape and the output dtype")
         opts = HostOpts(int(bool(neg_auto)), int(bool(legacy_numpy)), float(low), float(high), int(bool(lab_auto)), 0)
         self.check(self.lib.ss_chain_run_host(self.handle, C.byref(desc), src.ctypes.data_as(C.c_void_p),
                                               out.ctypes.data_as(C.c_void_p), C.byref(opts)))

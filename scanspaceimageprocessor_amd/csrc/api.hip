@@ -244,7 +244,22 @@ void parallel_memcpy(void* dst, const void* src, size_t n) {
   for (int t = 0; t < started; ++t) pool[t].join();
 }
 
+// Page-locked host memory (hipHostMalloc, hipHostRegister, torch's pinned tensors) needs no staging: the copy
+// engine reads and writes it directly.
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary pageable pointer: not an error of ours
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
 int copy_h2d(ss_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes >= ((size_t)1 << 20) && is_pinned_host(src)) {
+    SS_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return SS_OK;
+  }
   int rc = ensure_pinned(c);
   if (rc) return rc;
   size_t off = 0;
@@ -262,6 +277,11 @@ int copy_h2d(ss_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 
 int copy_d2h(ss_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes >= ((size_t)1 << 20) && is_pinned_host(dst)) {
+    SS_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+  }
   int rc = ensure_pinned(c);
   if (rc) return rc;
   // two-deep pipeline: the copy into one staging buffer overlaps the memcpy out of the other
@@ -625,6 +645,26 @@ int ss_free(ss_ctx* c, void* dev) {
     SS_HIP(c, hipStreamSynchronize(c->stream));
     SS_HIP(c, hipFree(dev));
   }
+  return SS_OK;
+}
+
+int ss_host_alloc(ss_ctx* c, uint64_t bytes, void** out_host) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!out_host || bytes == 0) return fail(c, SS_ERR_INVALID, "bad arguments");
+  SS_HIP(c, hipHostMalloc(out_host, bytes, hipHostMallocDefault));
+  return SS_OK;
+}
+
+int ss_host_free(ss_ctx* c, void* host) {
+  if (!host) return SS_OK;
+  if (c) {  // (a buffer may outlive its context: ctx == NULL frees without waiting for a stream)
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  hipError_t e = hipHostFree(host);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "hipHostFree failed: %s", hipGetErrorString(e));
   return SS_OK;
 }
 

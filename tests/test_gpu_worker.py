@@ -152,3 +152,33 @@ def test_worker_takes_the_decoders_uint16_output():
         ef, pf = w.process_array(as_float, "a.nef")
         np.testing.assert_array_equal(e16, ef)
         np.testing.assert_array_equal(p16, pf)
+
+
+def test_page_locked_host_buffers_are_copied_directly_with_the_same_result():
+    from gpu_util import DeviceBuffer
+    from scanspaceimageprocessor_amd import default_context
+    from scanspaceimageprocessor_amd.chain import make_desc
+
+    ctx = default_context()
+    rng = np.random.default_rng(3)
+    data = rng.random((600, 800, 3), dtype=np.float32)          # 5.8 MB: above the direct-copy threshold
+    pinned_in = ctx.pinned_empty(data.shape, np.float32)
+    pinned_in[...] = data
+    pinned_out = ctx.pinned_empty(data.shape, np.float32)
+    buf = DeviceBuffer(ctx, data.nbytes)
+    try:
+        ctx.upload(buf.ptr, pinned_in)
+        ctx.download(pinned_out, buf.ptr)
+        np.testing.assert_array_equal(pinned_out, data)
+        back = np.empty_like(data)
+        ctx.download(back, buf.ptr)                              # pageable destination: staged path
+        np.testing.assert_array_equal(back, data)
+    finally:
+        buf.free()
+    # the host entry point of the chain, pinned source against pageable source
+    desc = make_desc(600, 800, 1, ccm=(np.eye(3) * 0.9 + 0.03, 1, 3), gains=[1.1], usm=(40.0, 1.0, 0.0), final_clip=True,
+                     out="u16")
+    a, _ = ctx.chain_run_host(desc, pinned_in)
+    b, _ = ctx.chain_run_host(desc, data)
+    np.testing.assert_array_equal(a, b)
+    del pinned_in, pinned_out

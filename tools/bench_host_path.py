@@ -33,6 +33,10 @@ ccm = (np.eye(3) * 0.9 + 0.03, 1, 3)
 d16 = make_desc(H, W, 1, ccm=ccm, gains=[1.1], usm=(40.0, 1.0, 0.0), final_clip=True, out="u16")
 d32 = make_desc(H, W, 1, ccm=ccm, gains=[1.1], final_clip=True, out="f32")
 timeit("ss_chain_run_host ccm+gain+usm -> u16 (288 MB in, 144 out)", lambda: ctx.chain_run_host(d16, img))
+pin_in = ctx.pinned_empty(img.shape, np.float32)
+pin_in[...] = img
+pin_out = ctx.pinned_empty(img.shape, np.uint16)
+timeit("  the same between page-locked buffers (ctx.pinned_empty)", lambda: ctx.chain_run_host(d16, pin_in, out=pin_out))
 timeit("ss_chain_run_host ccm+gain -> f32 (288 MB in, 288 out)", lambda: ctx.chain_run_host(d32, img))
 timeit("editingTools.adjust_sharpen (f32 in, f32 out)", lambda: et.adjust_sharpen(img, 40.0, 1.0, 0.0))
 timeit("numpy copy of the image, for scale", lambda: img.copy())
