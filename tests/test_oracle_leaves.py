@@ -36,6 +36,22 @@ def test_white_and_black_in_lab():
     np.testing.assert_allclose(lv.XYZ_to_Lab(lv.D65_XYZ[None]), [[100.0, 0.0, 0.0]], atol=1e-12)
 
 
+def test_lab_of_the_srgb_primaries_against_published_values():
+    # CIELAB (D65) of the sRGB primaries and secondaries as commonly tabulated (e.g. Lindbloom's calculator, which
+    # uses an sRGB matrix with more digits than the 4-digit IEC one colour-science applies: agreement to ~0.03)
+    published = {
+        (1, 0, 0): (53.2408, 80.0925, 67.2032),
+        (0, 1, 0): (87.7347, -86.1827, 83.1793),
+        (0, 0, 1): (32.2970, 79.1875, -107.8602),
+        (1, 1, 0): (97.1393, -21.5537, 94.4780),
+        (0, 1, 1): (91.1132, -48.0875, -14.1312),
+        (1, 0, 1): (60.3242, 98.2343, -60.8249),
+    }
+    for rgb, lab in published.items():
+        got = lv.XYZ_to_Lab(lv.sRGB_to_XYZ(np.array([rgb], dtype=np.float64)))[0]
+        np.testing.assert_allclose(got, lab, atol=0.05)
+
+
 def test_lab_and_xyz_round_trips():
     rng = np.random.default_rng(0)
     rgb = rng.random((500, 3))
