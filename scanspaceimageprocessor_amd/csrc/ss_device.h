@@ -124,6 +124,7 @@ __device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2
 __device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ float vabs(float x) { return fabsf(x); }
 __device__ __forceinline__ float vcopysign(float m, float s) { return copysignf(m, s); }
 
@@ -132,6 +133,7 @@ __device__ __forceinline__ v2f hw_exp2(v2f x) { return v2f{hw_exp2(x.x), hw_exp2
 __device__ __forceinline__ v2f hw_sqrt(v2f x) { return v2f{hw_sqrt(x.x), hw_sqrt(x.y)}; }
 __device__ __forceinline__ v2f clamp01(v2f x) { return v2f{clamp01(x.x), clamp01(x.y)}; }
 __device__ __forceinline__ v2f clampf(v2f x, float lo, float hi) { return v2f{clampf(x.x, lo, hi), clampf(x.y, lo, hi)}; }
+__device__ __forceinline__ v2f med3(v2f x, v2f lo, v2f hi) { return v2f{med3(x.x, lo.x, hi.x), med3(x.y, lo.y, hi.y)}; }
 __device__ __forceinline__ v2f vabs(v2f x) { return v2f{fabsf(x.x), fabsf(x.y)}; }
 __device__ __forceinline__ v2f vcopysign(v2f m, v2f s) { return v2f{copysignf(m.x, s.x), copysignf(m.y, s.y)}; }
 
@@ -166,7 +168,11 @@ template <class V>
 __device__ __forceinline__ V lab_f(V t) {
   const V hi = hw_exp2(hw_log2(t) * (1.0f / 3.0f));
   const V lo = mad<V>(t, 841.0f / 108.0f, 16.0f / 116.0f);
-  return t > (V)(0.008856451679035631f) ? hi : lo;
+  // The line is the tangent of the cube root at the junction (value 6/29 there) and the cube root is concave:
+  // hi <= lo everywhere, both <= 6/29 below the junction and >= 6/29 above it, so the selected branch is the
+  // median of {hi, lo, 6/29}: one instruction instead of a compare and a select.  (t >= 0 here: X, Y, Z of
+  // non-negative linear RGB.)
+  return med3(hi, lo, (V)(24.0f / 116.0f));
 }
 template <class V>
 __device__ __forceinline__ V lab_finv(V f) {
@@ -516,8 +522,6 @@ __device__ __forceinline__ LabT<V> sh_on_lab(LabT<V> q, const ChainParams& P) {
   return q;
 }
 
-__device__ __forceinline__ float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-__device__ __forceinline__ v2f med3(v2f x, v2f lo, v2f hi) { return v2f{med3(x.x, lo.x, hi.x), med3(x.y, lo.y, hi.y)}; }
 
 // RGB (sRGB-encoded, as the reference assumes) in and out: _rgb_to_lab, the edit, _lab_to_rgb.
 // DECODED = true returns the sRGB decoding of that result instead: decode(clip(encode(x), 0, 1)) is
