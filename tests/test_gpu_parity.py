@@ -245,7 +245,7 @@ def test_neutral_settings_return_the_input_object():
 # ---- config 2 / config 4 ------------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("shape", [(3, 5), (33, 129), (200, 300), (257, 389)])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (2, 2), (3, 5), (33, 129), (200, 300), (257, 389)])
 @pytest.mark.parametrize("amount", [1.0, 50.0])
 def test_config2_ccm_gain_usm_u16(swatches, shape, amount):
     M_T, M_R = swatches
