@@ -16,10 +16,10 @@
 //                       Lock-free union with path halving.  Every write to a parent word in this kernel is an
 //                       atomicMin: parents only ever decrease, so no writer can undo another one's link
 //                       (plain stores, which reach memory late from a remote XCD's L2, did exactly that).
-//   mask_flatten_kernel pointer jumping, one launch per round until a round changes nothing: each word has
-//                       a single writer here, so plain stores are safe.  Afterwards every parent is a root.
-//   mask_area_kernel    areas per root: run lengths summed per lane while the root stays the same, then
-//                       over the lanes of a wave that share a root, one atomic per distinct root.
+//   mask_area_kernel    every run's parent becomes the root of its tree (each word has a single writer here, so
+//                       plain stores are safe), and areas per root: run lengths summed per lane while the root
+//                       stays the same, then over the lanes of a wave that share a root, one atomic per
+//                       distinct root.
 //   mask_apply_kernel   per row, the runs of components that are large enough are painted into a bitmap in
 //                       LDS, then the row's pixels under the bitmap are zeroed (coalesced) and counted.
 
@@ -53,7 +53,6 @@ struct MaskWork {
   int32_t* parent;
   int32_t* area;
   int32_t* rowcount;
-  int* flags;
   int cap;
   size_t slots;  // per image
   __host__ __device__ RunLists image(int b, int h) const {
@@ -199,38 +198,15 @@ __global__ __launch_bounds__(256) void mask_merge_kernel(const MaskWork work, in
   }
 }
 
-// One round of pointer jumping: parent[slot] <- its ancestor up to 8 levels up.  `flags[round]` is raised
-// while some run may still not point at a root; a round whose predecessor moved nothing returns at once (the
-// launcher issues a fixed number of rounds, on a fixed modest grid so that the idle ones cost microseconds).
-__global__ __launch_bounds__(256) void mask_flatten_kernel(const MaskWork work, int h, int round) {
-  if (round > 0 && work.flags[round - 1] == 0) return;
-  const RunLists R = work.image(blockIdx.y, h);
-  bool moved = false;
-  for (int y = blockIdx.x; y < h; y += gridDim.x) {
-    const int n = R.rowcount[y];
-    for (int k = threadIdx.x; k < n; k += 256) {
-      const int slot = y * work.cap + k;
-      const int p = R.parent[slot];
-      if (p == slot) continue;
-      int a = p, g = R.parent[a];
-#pragma unroll 1
-      for (int hop = 0; hop < 7 && g != a; ++hop) {  // up to 8 levels per round
-        a = g;
-        g = R.parent[a];
-      }
-      if (g != p) {
-        R.parent[slot] = g;
-        if (R.parent[g] != g) moved = true;  // not at a root yet (as far as this thread can see): another round
-      }
-    }
-  }
-  if (moved) work.flags[round] = 1;
-}
-
-// area[root] += length of every run below it (every slot starts out with its own length).  A thread keeps the sum for the root it saw last and sends it when the
-// root changes; what is left at the end is folded over the lanes that share a root, one atomic per distinct
-// root: a component that covers half the image (a backdrop) would otherwise put every one of its runs on a
-// single address.
+// parent[slot] <- the root of its tree, and area[root] += length of every run below it (every slot starts out
+// with its own length).
+// Roots: no union happens any more, so the forest only gets flatter while this kernel runs.  A thread follows
+// its run's path to the end (indices strictly decrease along a path, so the walk terminates) and writes its
+// own word, of which it is the only writer (plain store); whatever mix of old and new parents it reads on the
+// way, each is an ancestor.
+// Areas: a thread keeps the sum for the root it saw last and sends it when the root changes; what is left at
+// the end is folded over the lanes that share a root, one atomic per distinct root: a component that covers
+// half the image (a backdrop) would otherwise put every one of its runs on a single address.
 __global__ __launch_bounds__(256) void mask_area_kernel(const MaskWork work, int h) {
   const RunLists R = work.image(blockIdx.y, h);
   int root = -1, sum = 0;
@@ -243,6 +219,18 @@ __global__ __launch_bounds__(256) void mask_area_kernel(const MaskWork work, int
       for (int u = 0; u < U; ++u) {
         const int k = k0 + u * 256, slot = y * work.cap + k;
         p[u] = k < n ? R.parent[slot] : slot;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int slot = y * work.cap + k0 + u * 256;
+        if (p[u] == slot) continue;
+        int a = p[u], g = R.parent[a];
+        while (g != a) {
+          a = g;
+          g = R.parent[a];
+        }
+        if (a != p[u]) R.parent[slot] = a;
+        p[u] = a;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -333,15 +321,11 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(float* __restrict__ img
   }
 }
 
-// rounds of pointer jumping issued: a round divides every run's distance to its root by 8, so a chain of
-// 2^31 nodes (more than an image with int32 slots can hold) is flat after 11 rounds; one more confirms it
-constexpr int kFlattenRounds = 12;
-
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // byte offsets of the arrays inside the workspace
 struct MaskLayout {
-  size_t parent, area, rowcount, flags, total;  // (span sits at offset 0)
+  size_t parent, area, rowcount, total;  // (span sits at offset 0)
 };
 
 MaskLayout layout_of(int batch, int h, int w) {
@@ -350,8 +334,7 @@ MaskLayout layout_of(int batch, int h, int w) {
   l.parent = align256((size_t)batch * slots * 2 * sizeof(uint16_t));
   l.area = l.parent + align256((size_t)batch * slots * sizeof(int32_t));
   l.rowcount = l.area + align256((size_t)batch * slots * sizeof(int32_t));
-  l.flags = l.rowcount + align256((size_t)batch * h * sizeof(int32_t));
-  l.total = l.flags + align256((kFlattenRounds + 1) * sizeof(int));
+  l.total = l.rowcount + align256((size_t)batch * h * sizeof(int32_t));
   return l;
 }
 
@@ -365,7 +348,6 @@ MaskWork carve(void* workspace, int batch, int h, int w) {
   m.parent = reinterpret_cast<int32_t*>(p + l.parent);
   m.area = reinterpret_cast<int32_t*>(p + l.area);
   m.rowcount = reinterpret_cast<int32_t*>(p + l.rowcount);
-  m.flags = reinterpret_cast<int*>(p + l.flags);
   return m;
 }
 
@@ -378,10 +360,8 @@ hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shado
   if (h < 1 || w < 1 || w > kMaxWidth || batch < 1 || batch > 65535 || (int64_t)h * ((w + 1) / 2) > INT32_MAX)
     return hipErrorInvalidValue;
   const MaskWork work = carve(workspace, batch, h, w);
-  hipError_t e = hipMemsetAsync(work.flags, 0, (kFlattenRounds + 1) * sizeof(int), st);
-  if (e != hipSuccess) return e;
   if (count_dev) {
-    e = hipMemsetAsync(count_dev, 0, (size_t)batch * sizeof(unsigned long long), st);
+    hipError_t e = hipMemsetAsync(count_dev, 0, (size_t)batch * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
   }
   // (rows go to the x dimension of the grid, which has no 65535 limit)
@@ -391,8 +371,6 @@ hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shado
   const size_t up_bytes = (size_t)work.cap * sizeof(uint32_t);
   const int stage = up_bytes <= 48 * 1024;
   hipLaunchKernelGGL(mask_merge_kernel, dim3(row_blocks, batch), dim3(256), stage ? up_bytes : 0, st, work, h, stage);
-  for (int round = 0; round < kFlattenRounds; ++round)
-    hipLaunchKernelGGL(mask_flatten_kernel, dim3(row_blocks, batch), dim3(256), 0, st, work, h, round);
   const unsigned area_blocks = (unsigned)(h < 256 ? h : 256);
   hipLaunchKernelGGL(mask_area_kernel, dim3(area_blocks, batch), dim3(256), 0, st, work, h);
   hipLaunchKernelGGL(mask_apply_kernel, dim3(row_blocks, batch), dim3(256), 0, st, img, work, h, w, min_area,
