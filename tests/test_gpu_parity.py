@@ -449,3 +449,97 @@ def test_worker_threads_with_their_own_contexts_agree_with_serial_runs(swatches)
     assert not errors
     for a, b in zip(serial, results):
         np.testing.assert_array_equal(a, b)
+
+
+# ---- random stage combinations ------------------------------------------------------------------
+
+
+def _oracle_chain(img, M_T, M_R, neg, ccm_kw, gains, sh, usm, final_clip, out):
+    """The stages of a descriptor composed from the oracle's functions, in the kernel's stage order."""
+    x = img.astype(np.float64)
+    if neg is not None:
+        lo, inv = neg
+        x = 1.0 - np.clip((np.clip(x, 0, 1) - np.asarray(lo, np.float64)) * np.asarray(inv, np.float64), 0, 1)
+    if ccm_kw is not None:
+        x = lv.colour_correction(x, M_T, M_R, **ccm_kw)
+    for g in gains:
+        x = np.clip(x * np.asarray(g, np.float64), 0, 1)
+    if sh is not None:
+        x = oc.adjust_shadows_highlights_combined(x, sh[0], sh[1], sh[2])
+    if usm is not None:
+        x = oc.adjust_sharpen(x, usm[0], usm[1], usm[2])
+    if final_clip:
+        x = np.clip(x, 0, 1)
+    if out == "f32":
+        return x
+    enc = lv.eotf_inverse_sRGB(x)
+    if out == "f32_srgb":
+        return enc
+    scale = 65535.0 if out == "u16" else 255.0
+    return np.clip(enc * scale, 0, scale).astype(np.uint16 if out == "u16" else np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_stage_combinations(swatches, seed):
+    M_T, M_R = swatches
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(1, 70)), int(rng.integers(1, 300))
+    b = int(rng.integers(1, 3))
+    imgs = np.stack([inputs.linear_image(500 + seed * 3 + i, h, w) for i in range(b)])
+    neg = None
+    if rng.random() < 0.3:
+        lo = rng.uniform(0.0, 0.2, 3)
+        neg = (lo.astype(np.float32), (1.0 / rng.uniform(0.4, 0.9, 3)).astype(np.float32))
+    ccm_kw = [None, {}, {"method": "Cheung 2004", "terms": 5}, {"method": "Cheung 2004", "terms": 8},
+              {"method": "Finlayson 2015", "degree": 2}, {"method": "Cheung 2004", "terms": 14},
+              {"method": "Finlayson 2015", "degree": 3}][int(rng.integers(0, 7))]
+    if ccm_kw is not None and ccm_kw.get("method") == "Finlayson 2015":
+        neg = None  # the roots have unbounded slope at the zeros an inversion clips to: float32 cannot follow float64 there
+    gains = [rng.uniform(0.6, 1.6, 3) if rng.random() < 0.5 else float(rng.uniform(0.6, 1.6))
+             for _ in range(int(rng.integers(0, 4)))]
+    sh = usm = None
+    if rng.random() < 0.5:
+        # the GUI's range (amounts far above it saturate everything; the chroma branch they switch on is pinned by
+        # the reference vectors)
+        sh = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), 7.0)
+    if rng.random() < 0.6:
+        usm = (float(rng.choice([0.5, 20.0, 45.0, 80.0])), float(rng.choice([0.5, 1.0, 2.0, 2.5])),
+               float(rng.choice([0.0, 2.0])))
+    if (sh is not None or usm is not None) and not gains:
+        gains = [1.0]  # the reference clips to [0,1] before these stages
+    final_clip = bool(rng.random() < 0.7) or sh is not None or usm is not None
+    out = ["f32", "f32_srgb", "u16", "u8"][int(rng.integers(0, 4))]
+    high_order = ccm_kw is not None and (ccm_kw.get("terms", 3) > 8 or ccm_kw.get("degree", 1) >= 3)
+    if high_order and out in ("u16", "u8"):
+        out = "f32"  # their float32 error is a multiple of the 1e-5 bar (sum of |coefficient * term|), see the term tests
+    if out != "f32" and not final_clip and ccm_kw is not None:
+        final_clip = True  # encoded outputs of unclipped data are not a reference path
+    kw = dict(gains=gains, final_clip=final_clip, out=out)
+    if neg is not None:
+        kw["neg"] = neg
+    if ccm_kw is not None:
+        kw["ccm"] = fit(M_T, M_R, **ccm_kw)
+    if sh is not None:
+        kw["sh"] = sh
+    if usm is not None:
+        kw["usm"] = usm
+    got = run_chain_dev(imgs, **kw)
+    for i in range(b):
+        pos = imgs[i]
+        want = _oracle_chain(pos, M_T, M_R, neg, ccm_kw, gains, sh, usm, final_clip, out)
+        if out in ("u16", "u8"):
+            diff = np.abs(got[i].astype(np.int64) - want.astype(np.int64))
+            # A Lab edit leaves a dark channel of a bright pixel as the small difference of terms of size ~0.5:
+            # float32 keeps ~1e-7 of it, and both sRGB encodes multiply that by 12.92 on their linear segments
+            # (the Lab stage's own encode below 0.0031 linear = 0.04 encoded, the output encode of that below
+            # 0.2225): there, and only there, a 16-bit result may be 2 steps off.
+            allowed = np.where((want < 0.23 * 65535) & (out == "u16") & (sh is not None or usm is not None), 2, 1)
+            assert np.all(diff <= allowed), (seed, list(kw.keys()), int(diff.max()))
+        else:
+            # polynomial corrections of high order lose absolute accuracy with the size of their terms
+            tol = F32_TOL * (1 if ccm_kw is None or ccm_kw.get("terms", 3) <= 3 and ccm_kw.get("degree", 1) <= 1 else 4)
+            err = np.abs(got[i] - want)
+            # (the dark-channel effect described above, on a float output that is encoded a second time)
+            edited_and_encoded = out == "f32_srgb" and (sh is not None or usm is not None)
+            allowed = np.where((want < 0.23) & edited_and_encoded, 3 * tol, tol)
+            assert np.all(err <= allowed), (seed, out, ccm_kw, sh, usm, len(gains), float(err.max()))
