@@ -82,15 +82,16 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
 //
 // Strip walk: the tile grid of every image is cut into vertical segments of `seg_tiles` tiles, one tile
 // wide.  A workgroup walks a segment top to bottom, then takes the next free segment off a device-side
-// ticket counter (workgroups that share a CU do not progress at the same speed, so a fixed deal would
-// leave the fast ones idle at the end).  Consecutive tiles of a segment share 2r rows of halo: after a
+// ticket counter of its XCD (workgroups that share a CU do not progress at the same speed, so a fixed deal
+// would leave the fast ones idle at the end).  Consecutive tiles of a segment share 2r rows of halo: after a
 // tile's phase 3 the bottom 2r rows of both LDS planes are moved to the top (through registers, across
 // the tile's closing barrier), so only the first tile of a segment computes its upper halo.  Any
 // assignment of segments to workgroups is correct; the order only affects speed.
 struct StripWalk {
   int tiles_x, tiles_y, seg_tiles, segs_y;
   uint32_t n_segments;  // whole batch
-  uint32_t* ticket;     // next free segment; the launcher sets it to gridDim.x before every launch
+  uint32_t chunk;       // segments per XCD: XCD k owns segments [k * chunk, (k + 1) * chunk)
+  uint32_t* ticket;     // [8] segments already handed out of each XCD's chunk; the launcher clears them
 };
 
 #ifdef SS_USM_TRACE  // timing experiment: per-workgroup start / end clock and tile count
@@ -240,7 +241,32 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   F3 late_c[DEFER];
   int cur_img = -1;
   ImgParams ip;
-  TilePos cur, pend = seg_pos(blockIdx.x);
+  // Segments are dealt per XCD: each of the 8 XCDs has its own L2, so the workgroups of one XCD (workgroup i
+  // runs on XCD i % 8) work through one contiguous range of segments - neighbouring tile columns, whose halo
+  // columns overlap, and the segment rows below each other, whose halo rows do - and meet each other's halo
+  // pixels in their own L2 instead of fetching them from memory once per XCD.  A workgroup whose XCD's range is
+  // used up helps out in the next XCD's range, so the tail stays as short as with a single counter.  If the
+  // i % 8 rule ever did not hold, only the locality would be lost.
+  uint32_t probe = 0;  // ranges, counting from this workgroup's own, found exhausted so far (thread 0 only)
+  auto draw = [&]() -> uint32_t {
+    const uint32_t home = blockIdx.x & 7u;
+    while (probe < 8) {
+      const uint32_t k = (home + probe) & 7u;
+      const uint32_t begin = k * T.chunk;
+      if (begin < T.n_segments) {
+        const uint32_t left = T.n_segments - begin;
+        const uint32_t t = atomicAdd(&T.ticket[k], 1u);
+        if (t < (left < T.chunk ? left : T.chunk)) return begin + t;
+      }
+      ++probe;
+    }
+    return T.n_segments;  // nothing left anywhere: seg_pos() reports it as invalid
+  };
+  if (tid == 0) next_seg = draw();
+  __syncthreads();
+  const uint32_t first_seg = next_seg;
+  __syncthreads();  // (next_seg is written again at the end of the first tile's phase 1)
+  TilePos cur, pend = seg_pos(first_seg);
   cur.valid = false;
   for (;;) {
     if (pend.valid) issue_loads(pend);
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       const ChainParams& P = params_now();
       const bool last_of_seg = cur.ty + 1 >= cur.ty_end;
       uint32_t drawn = 0;
-      if (last_of_seg && tid == 0) drawn = atomicAdd(T.ticket, 1u);
+      if (last_of_seg && tid == 0) drawn = draw();
       const int img = cur.img, x0 = cur.x0, y0 = cur.ty * TH;
       if (img != cur_img) {
         ip = load_img_params(P, img);
@@ -611,9 +637,10 @@ static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* s
   const int64_t n_segments = (int64_t)T.tiles_x * T.segs_y * batch;
   if (n_segments > INT32_MAX) return hipErrorInvalidValue;
   T.n_segments = (uint32_t)n_segments;
+  T.chunk = (T.n_segments + 7) / 8;
   T.ticket = ticket;
   const unsigned blocks = (unsigned)(n_segments < cap ? n_segments : cap);
-  hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ticket), (int)blocks, 1, st);
+  hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ticket), 0, 8, st);
   if (me != hipSuccess) return me;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(USM_NT), lds, st, P, T, src, dst);
   return hipGetLastError();
