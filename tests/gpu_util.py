@@ -1,6 +1,5 @@
 """Helpers for the -m gpu parity tests: everything goes through the C ABI (ctypes)."""
 
-import ctypes as C
 
 import numpy as np
 
