@@ -394,7 +394,7 @@ int ss_ctx_create(int device, ss_ctx** out_ctx) {
   c->stream = c->own_stream;
   e = hipMalloc(reinterpret_cast<void**>(&c->usm_ticket), 256);
   if (e != hipSuccess) {
-    hipStreamDestroy(c->own_stream);
+    (void)hipStreamDestroy(c->own_stream);
     delete c;
     return fail(nullptr, SS_ERR_NOMEM, "hipMalloc of the work-queue counter failed: %s", hipGetErrorString(e));
   }
@@ -408,23 +408,23 @@ int ss_ctx_create(int device, ss_ctx** out_ctx) {
 
 void ss_ctx_destroy(ss_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  if (c->ws_samples) hipFree(c->ws_samples);
-  if (c->ws_small) hipFree(c->ws_small);
-  if (c->usm_ticket) hipFree(c->usm_ticket);
-  if (c->ws_stage) hipFree(c->ws_stage);
-  if (c->ws_mask) hipFree(c->ws_mask);
-  if (c->host_src) hipFree(c->host_src);
-  if (c->host_dst) hipFree(c->host_dst);
-  if (c->host_neg) hipFree(c->host_neg);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ws_samples) (void)hipFree(c->ws_samples);
+  if (c->ws_small) (void)hipFree(c->ws_small);
+  if (c->usm_ticket) (void)hipFree(c->usm_ticket);
+  if (c->ws_stage) (void)hipFree(c->ws_stage);
+  if (c->ws_mask) (void)hipFree(c->ws_mask);
+  if (c->host_src) (void)hipFree(c->host_src);
+  if (c->host_dst) (void)hipFree(c->host_dst);
+  if (c->host_neg) (void)hipFree(c->host_neg);
   for (int i = 0; i < 2; ++i) {
-    if (c->pinned[i]) hipHostFree(c->pinned[i]);
-    if (c->pinned_free[i]) hipEventDestroy(c->pinned_free[i]);
+    if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+    if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
   }
-  if (c->t0) hipEventDestroy(c->t0);
-  if (c->t1) hipEventDestroy(c->t1);
-  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  if (c->t0) (void)hipEventDestroy(c->t0);
+  if (c->t1) (void)hipEventDestroy(c->t1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
