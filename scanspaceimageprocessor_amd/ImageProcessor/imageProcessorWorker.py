@@ -344,11 +344,9 @@ class ImageCorrectionWorker:
         if self.image_writer is not None:
             self.image_writer(out_path, encoded, ext)
             return
-        if ext == '.exr':
-            raise NotImplementedError("EXR export goes through OpenImageIO in the reference; supply image_writer")
         from .imageWriters import write_image
 
-        write_image(out_path, encoded, ext, self.jpeg_quality)
+        write_image(out_path, encoded, ext, self.jpeg_quality, exr_colorspace=self.exr_colorspace)
 
     def construct_export_path(self, img_path: str) -> str:
         base = os.path.splitext(os.path.basename(img_path))[0]

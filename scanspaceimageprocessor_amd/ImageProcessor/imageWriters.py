@@ -10,8 +10,12 @@ uses those libraries when they can be imported and otherwise writes the two loss
   baseline set only);
 * PNG: 8-bit RGB (or grey), zlib-compressed scanlines with filter type 0.
 
-JPEG needs a real encoder (imageio or Pillow); EXR in a target colour space needs OpenImageIO: without them
-those formats raise, they are not approximated.
+* OpenEXR: single-part scanline file, 32-bit float channels B, G, R, no compression: what the reference's
+  ``ImageSpec(w, h, 3, TypeFloat)`` image holds when the target colour space is the source one ("sRGB", the
+  default of the network mode, networkProcessor.py:2755: ``colorconvert("sRGB", "sRGB")`` is the identity).
+
+JPEG needs a real encoder (imageio or Pillow); EXR in any other target colour space needs OpenImageIO's
+colour management: without them those cases raise, they are not approximated.
 """
 
 from __future__ import annotations
@@ -124,8 +128,89 @@ def write_png(path, arr, compress_level=6):
         f.write(chunk(b"IEND", b""))
 
 
-def write_image(path, arr, ext, jpeg_quality=100):
-    """The worker's export step (imageProcessorWorker.py:915-920) for '.jpg' / '.jpeg' / '.png' / '.tiff'."""
+def _exr_attr(name, typ, payload):
+    return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+
+
+def write_exr(path, arr, colorspace="sRGB"):
+    """Uncompressed scanline OpenEXR (version 2) of a (H, W, 3) float image: FLOAT channels B, G, R."""
+    img = np.asarray(arr)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError(f"unsupported image for this container: shape {img.shape}")
+    img = np.ascontiguousarray(img, dtype="<f4")
+    h, w, _ = img.shape
+    chlist = b"".join(n + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for n in (b"B", b"G", b"R")) + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    header = b"".join([
+        _exr_attr("channels", "chlist", chlist),
+        _exr_attr("compression", "compression", b"\0"),
+        _exr_attr("dataWindow", "box2i", box),
+        _exr_attr("displayWindow", "box2i", box),
+        _exr_attr("lineOrder", "lineOrder", b"\0"),
+        _exr_attr("oiio:ColorSpace", "string", colorspace.encode()),
+        _exr_attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)),
+        _exr_attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0)),
+        _exr_attr("screenWindowWidth", "float", struct.pack("<f", 1.0)),
+        b"\0",
+    ])
+    line_bytes = 3 * w * 4
+    first_block = 8 + len(header) + 8 * h
+    offsets = first_block + np.arange(h, dtype="<u8") * (8 + line_bytes)
+    blocks = np.empty((h, 8 + line_bytes), dtype=np.uint8)
+    blocks[:, 0:4] = np.arange(h, dtype="<i4").view(np.uint8).reshape(h, 4)
+    blocks[:, 4:8] = np.frombuffer(struct.pack("<i", line_bytes), dtype=np.uint8)
+    planar = np.ascontiguousarray(img[:, :, ::-1].transpose(0, 2, 1))  # (H, [B, G, R], W)
+    blocks[:, 8:] = planar.view(np.uint8).reshape(h, line_bytes)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Ii", 20000630, 2))
+        f.write(header)
+        f.write(offsets.tobytes())
+        f.write(blocks.tobytes())
+
+
+def read_exr(path):
+    """Reader for the files ``write_exr`` makes (uncompressed FLOAT scanlines); used to check them.
+    Returns ``(array (H, W, 3) float32 in R, G, B order, attributes)``."""
+    raw = open(path, "rb").read()
+    magic, version = struct.unpack_from("<Ii", raw, 0)
+    if magic != 20000630 or version & 0xFF != 2 or version & ~0xFF:
+        raise ValueError("not a single-part scanline OpenEXR file")
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        end = raw.index(b"\0", pos)
+        name = raw[pos:end].decode()
+        pos = end + 1
+        end = raw.index(b"\0", pos)
+        typ = raw[pos:end].decode()
+        pos = end + 1
+        (size,) = struct.unpack_from("<i", raw, pos)
+        attrs[name] = (typ, raw[pos + 4:pos + 4 + size])
+        pos += 4 + size
+    pos += 1
+    if attrs["compression"][1] != b"\0":
+        raise ValueError("compressed OpenEXR")
+    names, p, ch = [], 0, attrs["channels"][1]
+    while ch[p] != 0:
+        end = ch.index(b"\0", p)
+        names.append(ch[p:end].decode())
+        (ptype,) = struct.unpack_from("<i", ch, end + 1)
+        if ptype != 2:
+            raise ValueError("only FLOAT channels")
+        p = end + 1 + 16
+    xmin, ymin, xmax, ymax = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = xmax - xmin + 1, ymax - ymin + 1
+    offsets = np.frombuffer(raw, dtype="<u8", count=h, offset=pos)
+    out = np.empty((h, w, 3), dtype=np.float32)
+    for off in offsets:
+        y, size = struct.unpack_from("<ii", raw, int(off))
+        line = np.frombuffer(raw, dtype="<f4", count=len(names) * w, offset=int(off) + 8).reshape(len(names), w)
+        for k, n in enumerate(names):
+            out[y - ymin, :, "RGB".index(n)] = line[k]
+    return out, {k: v[1].decode() for k, v in attrs.items() if v[0] == "string"}
+
+
+def write_image(path, arr, ext, jpeg_quality=100, exr_colorspace=None):
+    """The worker's export step (imageProcessorWorker.py:915-920) for '.jpg' / '.jpeg' / '.png' / '.tiff' / '.exr'."""
     ext = ext.lower()
     if ext in (".jpg", ".jpeg"):
         try:
@@ -155,8 +240,14 @@ def write_image(path, arr, ext, jpeg_quality=100):
                 tw.write(arr)
         except ImportError:
             write_tiff(path, arr)
+    elif ext == ".exr":
+        # export_image_exr (imageProcessorWorker.py:617-662): float image tagged sRGB, converted to the target space
+        target = exr_colorspace or "sRGB"
+        if target != "sRGB":
+            raise NotImplementedError(f"EXR export to colour space {target!r} needs OpenImageIO's colorconvert")
+        write_exr(path, arr, "sRGB")
     else:
-        raise NotImplementedError(f"no writer for {ext}: EXR export goes through OpenImageIO in the reference")
+        raise NotImplementedError(f"no writer for {ext}")
 
 
 # ---- chart calibration files -----------------------------------------------------------------------------

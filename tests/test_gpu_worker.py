@@ -114,6 +114,21 @@ def test_run_writes_files_with_the_built_in_containers(tmp_path):
                 got = np.asarray(im)
         assert got.dtype == want.dtype
         assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int64))) <= 1
+    # EXR: the float image itself (linear, clipped), tagged sRGB; another target colour space is refused loudly
+    out_dir = tmp_path / "exr"
+    out_dir.mkdir()
+    w = ipw.ImageCorrectionWorker(["shot.nef"], M_T, str(out_dir), None, output_format=".exr", exr_colorspace="sRGB")
+    w.raw_loader = lambda path: img
+    w.run()
+    got, attrs = iw.read_exr(str(out_dir / "shot.exr"))
+    assert attrs["oiio:ColorSpace"] == "sRGB"
+    assert np.max(np.abs(got - oc.worker_chart_path(img, M_T, M_R))) <= 1e-5
+    w = ipw.ImageCorrectionWorker(["shot.nef"], M_T, str(out_dir), None, output_format=".exr", exr_colorspace="ACEScg")
+    w.raw_loader = lambda path: img
+    states = []
+    w.signals.status.connect(lambda *a: states.append(a[1]))
+    w.run()
+    assert states == ["started", "error"]
 
 
 def test_unpack_u16_is_numpys_division_bit_for_bit():

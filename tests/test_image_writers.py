@@ -1,5 +1,7 @@
 """File containers written without the reference's I/O libraries, and the calibration file format."""
 
+import importlib.util
+
 import numpy as np
 import pytest
 
@@ -40,8 +42,11 @@ def test_write_image_dispatch_and_rejections(tmp_path):
     arr = np.zeros((4, 5, 3), np.uint8)
     iw.write_image(str(tmp_path / "x.tiff"), arr, ".tiff")
     iw.write_image(str(tmp_path / "x.png"), arr, ".png")
+    iw.write_image(str(tmp_path / "x.exr"), arr.astype(np.float32), ".exr")
+    with pytest.raises(NotImplementedError):   # another target colour space needs OpenImageIO's colour management
+        iw.write_image(str(tmp_path / "z.exr"), arr.astype(np.float32), ".exr", exr_colorspace="ACEScg")
     with pytest.raises(NotImplementedError):
-        iw.write_image(str(tmp_path / "x.exr"), arr.astype(np.float32), ".exr")
+        iw.write_image(str(tmp_path / "x.bmp"), arr, ".bmp")
     with pytest.raises(ValueError):
         iw.write_tiff(str(tmp_path / "y.tiff"), arr.astype(np.float32))
     with pytest.raises(ValueError):
@@ -64,3 +69,26 @@ def test_calibration_files(tmp_path):
     np.save(str(tmp_path / "obj.npy"), np.array([{"a": 1}], dtype=object), allow_pickle=True)
     with pytest.raises(ValueError):
         iw.load_calibration(str(tmp_path / "obj.npy"))
+
+
+def test_exr_round_trip_and_layout(tmp_path):
+    rng = np.random.default_rng(4)
+    arr = (rng.random((7, 11, 3)) * 3.0 - 0.5).astype(np.float32)   # EXR holds unclipped linear data
+    arr[0, 0] = [np.float32(0.0), np.float32(1.0), np.float32(65504.0)]
+    path = str(tmp_path / "a.exr")
+    iw.write_exr(path, arr)
+    back, attrs = iw.read_exr(path)
+    np.testing.assert_array_equal(back, arr)
+    assert attrs["oiio:ColorSpace"] == "sRGB"
+    raw = open(path, "rb").read()
+    assert raw[:8] == bytes([0x76, 0x2F, 0x31, 0x01, 2, 0, 0, 0])          # magic, version 2, no flags
+    # header, one offset per scanline, one block per scanline: y, byte count, B row, G row, R row
+    assert len(raw) == raw.index(b"screenWindowWidth") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1 + 8 * 7 + 7 * (8 + 132)
+    first = int(np.frombuffer(raw, "<u8", 1, raw.index(b"screenWindowWidth") + 33)[0])
+    y, n = np.frombuffer(raw, "<i4", 2, first)
+    assert (y, n) == (0, 132)
+    np.testing.assert_array_equal(np.frombuffer(raw, "<f4", 11, first + 8), arr[0, :, 2])   # B first
+    if importlib.util.find_spec("OpenImageIO"):
+        import OpenImageIO as oiio
+
+        np.testing.assert_array_equal(np.asarray(oiio.ImageBuf(path).get_pixels(oiio.FLOAT)), arr)
