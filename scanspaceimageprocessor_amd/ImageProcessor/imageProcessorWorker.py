@@ -349,8 +349,39 @@ class ImageCorrectionWorker:
         write_image(out_path, encoded, ext, self.jpeg_quality, exr_colorspace=self.exr_colorspace)
 
     def construct_export_path(self, img_path: str) -> str:
-        base = os.path.splitext(os.path.basename(img_path))[0]
-        return os.path.join(self.output_folder, base + self.output_format)
+        """Reference imageProcessorWorker.py:664-746: the server's path in network mode, else the naming schema
+        (when the host application supplies ``fileNamingSchema.apply_naming_schema``; any failure falls back to
+        the default name, as in the reference), else the legacy rules (original file name, or
+        ``name_base_<sequence>`` from ``rename_map``)."""
+        default_fn = os.path.splitext(os.path.basename(img_path))[0] + self.output_format
+        if self.from_network:
+            if self.network_output_path:
+                return self.network_output_path
+            if getattr(self, "use_original_filenames", False) or not self.name_base:
+                return os.path.join(self.output_folder, default_fn)
+            seq = self.rename_map.get(img_path, 1) if self.rename_map else 1
+            return os.path.join(self.output_folder, f"{self.name_base}_{seq:0{self.padding}d}{self.output_format}")
+        if self.use_export_schema and self.export_schema:
+            try:
+                from fileNamingSchema import apply_naming_schema  # the host application's module
+
+                out_path = apply_naming_schema(schema=self.export_schema, input_path=img_path,
+                                               output_base_dir=self.output_folder, custom_name=self.custom_name or "",
+                                               image_number=self.rename_map.get(img_path, 1),
+                                               output_extension=self.output_format, root_folder=self.root_folder or "",
+                                               group_name=self.group_name or "")
+                out_dir = os.path.dirname(out_path)
+                if out_dir and out_dir != self.output_folder:
+                    os.makedirs(out_dir, exist_ok=True)
+                return out_path
+            except Exception as e:
+                self.signals.log.emit(f"[Schema Error] Failed to apply naming schema for {img_path}: {e}")
+                return os.path.join(self.output_folder, default_fn)
+        if not getattr(self, "use_original_filenames", False):
+            seq = self.rename_map.get(img_path)
+            if seq is not None and self.name_base:
+                return os.path.join(self.output_folder, f"{self.name_base}_{seq:0{self.padding}d}{self.output_format}")
+        return os.path.join(self.output_folder, default_fn)
 
     # ------------------------------------------------------------------ main loop
 

@@ -197,3 +197,27 @@ def test_page_locked_host_buffers_are_copied_directly_with_the_same_result():
     b, _ = ctx.chain_run_host(desc, data)
     np.testing.assert_array_equal(a, b)
     del pinned_in, pinned_out
+
+
+def test_saved_job_runs_end_to_end(tmp_path):
+    from scanspaceimageprocessor_amd.ImageProcessor import imageWriters as iw
+    from scanspaceimageprocessor_amd.ImageProcessor.jobs import ProcessingJob, worker_from_job
+
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    raw16 = (inputs.linear_image(31, 80, 120) * 65535.0).astype(np.uint16)
+    out_path = str(tmp_path / "out" / "a.tiff")
+    (tmp_path / "out").mkdir()
+    text = ProcessingJob("job-1", "/data/a.nef", out_path, M_T.tolist(),
+                         {"output_format": ".tiff", "tiff_bitdepth": 16, "exposure_adj": 0.25}).to_json()
+    states = []
+    sig = ipw.WorkerSignals()
+    sig.status.connect(lambda *a: states.append(a))
+    w = worker_from_job(ProcessingJob.from_json(text), sig)
+    w.raw_loader = lambda path: raw16                       # the decoder's 16-bit image
+    w.run()
+    assert states[0] == ("started",) and states[-1][1] == "finished" and states[-1][3] == out_path
+    img = np.array(raw16, dtype=np.float32) / 65535.0
+    want = oc.encode_image(oc.worker_chart_path(img, M_T, M_R, exposure_adj=0.25), ".tiff", 16)
+    got = iw.read_tiff(out_path)
+    assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int64))) <= 1

@@ -1,0 +1,81 @@
+"""The job record of the reference's network mode (networkProcessor.py:507-526) and its translation into a worker
+(networkProcessor.py:2752-2806); output naming rules (imageProcessorWorker.py:664-746).  Host logic only."""
+
+import json
+import sys
+import types
+
+import numpy as np
+
+from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as ipw
+from scanspaceimageprocessor_amd.ImageProcessor.jobs import ProcessingJob, worker_from_job
+
+
+def test_job_json_round_trip():
+    sw = np.linspace(0.05, 0.9, 72).reshape(24, 3).tolist()
+    job = ProcessingJob("j1", "/in/a.nef", "/out/a.tiff", sw, {"output_format": ".tiff", "tiff_bitdepth": 16},
+                        created_time=12.5)
+    back = ProcessingJob.from_json(job.to_json())
+    assert back == job
+    assert set(json.loads(job.to_json())) == {"job_id", "image_path", "output_path", "swatches", "settings",
+                                               "created_time", "start_time", "timeout"}
+    assert back.timeout == 300.0 and back.start_time is None
+
+
+def test_worker_from_job_applies_the_reference_defaults():
+    w = worker_from_job(ProcessingJob("j", "/in/a.nef", "/out/sub/a.jpg", None, {}))
+    assert (w.images, w.output_folder, w.network_output_path) == (["/in/a.nef"], "/out/sub", "/out/sub/a.jpg")
+    assert w.from_network and not w.use_chart and w.swatches is None
+    assert (w.jpeg_quality, w.output_format, w.tiff_bitdepth, w.exr_colorspace) == (100, ".jpg", 8, "sRGB")
+    assert (w.exposure_adj, w.shadow_adj, w.highlight_adj, w.white_balance_adj) == (0.0, 0.0, 0.0, 5500)
+    assert (w.denoise_strength, w.sharpen_amount, w.use_export_schema) == (0.0, 0.0, False)
+    assert w.construct_export_path("/in/a.nef") == "/out/sub/a.jpg"     # the server's path wins in network mode
+
+
+def test_worker_from_job_settings_and_white_balance_switch():
+    sw = np.full((24, 3), 0.5).tolist()
+    st = {"output_format": ".tiff", "tiff_bitdepth": 16, "exposure_adj": 0.3, "shadow_adj": 12.0, "highlight_adj": -5.0,
+          "white_balance_adj": 4200, "sharpen_amount": 30.0, "jpeg_quality": 90, "group_name": "g"}
+    w = worker_from_job(ProcessingJob("j", "a.nef", "/o/a.tiff", sw, st))
+    assert w.use_chart and w.white_balance_adj == 5500      # white balance is ignored unless enabled
+    assert (w.exposure_adj, w.shadow_adj, w.highlight_adj, w.sharpen_amount) == (0.3, 12.0, -5.0, 30.0)
+    assert (w.output_format, w.tiff_bitdepth, w.jpeg_quality, w.group_name) == (".tiff", 16, 90, "g")
+    w = worker_from_job(ProcessingJob("j", "a.nef", "/o/a.tiff", sw, dict(st, enable_white_balance=True)))
+    assert w.white_balance_adj == 4200
+
+
+def test_export_path_rules(tmp_path, monkeypatch):
+    out = str(tmp_path)
+    mk = lambda **kw: ipw.ImageCorrectionWorker(["/in/IMG_0042.nef"], None, out, None, output_format=".png",
+                                                use_chart=False, **kw)
+    p = "/in/IMG_0042.nef"
+    assert mk().construct_export_path(p) == f"{out}/IMG_0042.png"
+    w = mk(rename_map={p: 7}, name_base="scan", padding=4)
+    assert w.construct_export_path(p) == f"{out}/scan_0007.png"
+    w.use_original_filenames = True
+    assert w.construct_export_path(p) == f"{out}/IMG_0042.png"
+    assert mk(rename_map={p: 7}).construct_export_path(p) == f"{out}/IMG_0042.png"          # no base name
+    # network mode without a server path: sequence defaults to 1
+    w = mk(from_network=True, name_base="scan", padding=3)
+    assert w.construct_export_path(p) == f"{out}/scan_001.png"
+    # a naming schema needs the host application's module; without it the default name is used and the error logged
+    logs = []
+    w = mk(export_schema="[r]/[n]", use_export_schema=True)
+    w.signals.log.connect(logs.append)
+    assert w.construct_export_path(p) == f"{out}/IMG_0042.png"
+    assert logs and logs[0].startswith("[Schema Error]")
+    # ... and with it, the schema's answer (directories are created)
+    mod = types.ModuleType("fileNamingSchema")
+    seen = {}
+
+    def apply_naming_schema(**kw):
+        seen.update(kw)
+        return f"{out}/deep/er/x.png"
+
+    mod.apply_naming_schema = apply_naming_schema
+    monkeypatch.setitem(sys.modules, "fileNamingSchema", mod)
+    w = mk(export_schema="[r]/[n]", use_export_schema=True, custom_name="c", group_name="g", rename_map={p: 3})
+    assert w.construct_export_path(p) == f"{out}/deep/er/x.png"
+    assert (tmp_path / "deep" / "er").is_dir()
+    assert seen == dict(schema="[r]/[n]", input_path=p, output_base_dir=out, custom_name="c", image_number=3,
+                        output_extension=".png", root_folder="", group_name="g")
