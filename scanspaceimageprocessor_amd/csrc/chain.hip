@@ -70,7 +70,15 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
       const uint32_t g = base + k * 256 + threadIdx.x;
       if (g < n_groups) {
 #pragma unroll
-        for (int j = 0; j < G; ++j) in[k][j] = s[g * G + j];
+        for (int j = 0; j < G; ++j) {
+          // streaming loads only where one access covers whole cache lines across the wave (G = 1: lanes 12 bytes
+          // apart); with G > 1 a line is completed by several accesses and has to stay cached in between
+          if constexpr (G == 1) {
+            in[k][j] = load_stream(s + (g * G + j));
+          } else {
+            in[k][j] = s[g * G + j];
+          }
+        }
       }
     }
     // the K*G = 4 pixels of this lane go through the stages as two packed pairs (lanes past the end of the
@@ -96,19 +104,19 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
       if (g < n_groups) {
         const Px* o = res + k * G;
         if constexpr (G == 1) {
-          reinterpret_cast<F3*>(d)[g] = F3{o[0].r, o[0].g, o[0].b};
+          store_stream(reinterpret_cast<F3*>(d) + g, F3{o[0].r, o[0].g, o[0].b});
         } else if constexpr (G == 2) {
           U3 q;
           q.x = quant16(o[0].r) | (quant16(o[0].g) << 16);
           q.y = quant16(o[0].b) | (quant16(o[1].r) << 16);
           q.z = quant16(o[1].g) | (quant16(o[1].b) << 16);
-          reinterpret_cast<U3*>(d)[g] = q;
+          store_stream(reinterpret_cast<U3*>(d) + g, q);
         } else {
           U3 q;
           q.x = quant8(o[0].r) | (quant8(o[0].g) << 8) | (quant8(o[0].b) << 16) | (quant8(o[1].r) << 24);
           q.y = quant8(o[1].g) | (quant8(o[1].b) << 8) | (quant8(o[2].r) << 16) | (quant8(o[2].g) << 24);
           q.z = quant8(o[2].b) | (quant8(o[3].r) << 8) | (quant8(o[3].g) << 16) | (quant8(o[3].b) << 24);
-          reinterpret_cast<U3*>(d)[g] = q;
+          store_stream(reinterpret_cast<U3*>(d) + g, q);
         }
       }
     }
@@ -134,8 +142,9 @@ __global__ __launch_bounds__(256) void unpack_u16_kernel(const uint16_t* __restr
                                                          uint64_t n) {
   const uint64_t n8 = n / 8;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * 256) {
-    const uint4 v = reinterpret_cast<const uint4*>(src)[i];
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(src) + 4 * i;
+    const uint32_t w[4] = {__builtin_nontemporal_load(sp), __builtin_nontemporal_load(sp + 1),
+                           __builtin_nontemporal_load(sp + 2), __builtin_nontemporal_load(sp + 3)};
     float f[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kRowThreads) void mask_runs_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       const int x = x0 + k * kRowThreads + tid;
-      m[k] = x < w && is_candidate(src[x], lo, hi);
+      m[k] = x < w && is_candidate(load_stream(src + x), lo, hi);
     }
 #pragma unroll
     for (int k = 0; k < P; ++k) {

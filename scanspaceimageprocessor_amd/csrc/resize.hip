@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kTileThreads) void resize_area_tiled_kernel(const f
     for (int k = 0; k < kTileVecs; ++k) {
       const int f = (tid + k * kTileThreads) * 4;
       if (f + 4 <= n_floats) {
+        // (cached loads: the strips' 16-byte accesses are not line-aligned, neighbouring ones complete a line)
         const F4 v = *reinterpret_cast<const F4*>(row + f);
         acc[k][0] = fmaf(v.x, beta, acc[k][0]);
         acc[k][1] = fmaf(v.y, beta, acc[k][1]);

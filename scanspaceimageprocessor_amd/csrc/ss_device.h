@@ -735,6 +735,26 @@ struct __attribute__((aligned(4))) U3 {
   uint32_t x, y, z;
 };
 
+// Streaming ("nontemporal") forms for data that is touched once: the caches are told not to keep it, which is
+// worth ~10 % on the pointwise chain (5.6 -> 6.1 TB/s for 12 B in + 12 B out per pixel).  The three dwords are
+// merged back into one dwordx3 access by the compiler.
+__device__ __forceinline__ F3 load_stream(const F3* p) {
+  const float* q = reinterpret_cast<const float*>(p);
+  return F3{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2)};
+}
+__device__ __forceinline__ void store_stream(F3* p, const F3 v) {
+  float* q = reinterpret_cast<float*>(p);
+  __builtin_nontemporal_store(v.x, q);
+  __builtin_nontemporal_store(v.y, q + 1);
+  __builtin_nontemporal_store(v.z, q + 2);
+}
+__device__ __forceinline__ void store_stream(U3* p, const U3 v) {
+  uint32_t* q = reinterpret_cast<uint32_t*>(p);
+  __builtin_nontemporal_store(v.x, q);
+  __builtin_nontemporal_store(v.y, q + 1);
+  __builtin_nontemporal_store(v.z, q + 2);
+}
+
 // OpenCV BORDER_REFLECT (fedcba|abcdefgh|hgfedcb) coordinate map (cv::borderInterpolate)
 __device__ __forceinline__ int reflect_coord(int p, int len) {
   if (len == 1) return 0;

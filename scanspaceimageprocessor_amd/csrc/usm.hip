@@ -43,8 +43,8 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
   const size_t px = (size_t)y * W + x;
   if constexpr (OUT == SS_OUT_F32_LINEAR || OUT == SS_OUT_F32_SRGB) {
     F3* d = reinterpret_cast<F3*>(dst_img) + px;
-    d[0] = F3{o0.r, o0.g, o0.b};
-    if (two) d[1] = F3{o1.r, o1.g, o1.b};
+    store_stream(d, F3{o0.r, o0.g, o0.b});
+    if (two) store_stream(d + 1, F3{o1.r, o1.g, o1.b});
   } else if constexpr (OUT == SS_OUT_U16_SRGB) {
     char* d = reinterpret_cast<char*>(dst_img) + px * 6;
     if (two && ((px * 6) & 3) == 0) {
@@ -52,7 +52,7 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
       q.x = q16(o0.r) | (q16(o0.g) << 16);
       q.y = q16(o0.b) | (q16(o1.r) << 16);
       q.z = q16(o1.g) | (q16(o1.b) << 16);
-      *reinterpret_cast<U3*>(d) = q;
+      store_stream(reinterpret_cast<U3*>(d), q);
     } else {
       uint16_t* h = reinterpret_cast<uint16_t*>(d);
       h[0] = (uint16_t)q16(o0.r);
