@@ -38,9 +38,9 @@ HBM_PEAK_GBS = 8000.0
 ALGO_BYTES_PER_PX = 18.0  # 12 in (float32 RGB) + 6 out (uint16 RGB)
 # HBM traffic of the unsharp-mask kernel per pixel, from the rocprofv3 PMC passes kept under profiles/
 # (FETCH_SIZE doubled as gfx950 needs, calibrated on the pointwise kernel's known 12 B/px; WRITE_SIZE as read):
-# 12.83 B/px fetched (what is left of the tile halos after the per-XCD deal of segments; 14.85 before it) +
-# 6.02 B/px written.  It cannot be collected inside this process; re-measure it when the kernel's tiling changes.
-MEASURED_TRAFFIC_BYTES_PER_PX = 18.85
+# 12.68 B/px fetched (what is left of the tile halos after the per-XCD deal of segments; 14.85 before it) +
+# 6.20 B/px written (streaming stores).  It cannot be collected inside this process; re-measure it when the kernel's tiling changes.
+MEASURED_TRAFFIC_BYTES_PER_PX = 18.88
 
 
 def synthetic_swatches():
@@ -254,7 +254,7 @@ def main():
                 "achieved": round(achieved_gbs, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                 "traffic": round((24.0 if config5 else MEASURED_TRAFFIC_BYTES_PER_PX) * px_per_launch),
-                "traffic_note": ("bytes per launch = 24.0 B/px" if config5 else "bytes per launch = 18.85 B/px")
+                "traffic_note": ("bytes per launch = 24.0 B/px" if config5 else "bytes per launch = 18.88 B/px")
                                 + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) x px_per_launch",
                 "algorithmic_bytes_per_px": algo_bytes,
                 "px_per_launch": px_per_launch, "kernel_ms": round(kernel_ms, 4),
