@@ -33,7 +33,7 @@ struct ss_ctx {
   size_t ws_samples_bytes = 0;
   void* ws_small = nullptr;  // histograms, select state, partials
   size_t ws_small_bytes = 0;
-  uint32_t* usm_ticket = nullptr;  // segment counter of the unsharp-mask kernel's work queue
+  uint32_t* usm_ticket = nullptr;  // per-XCD segment counters of the unsharp-mask kernel's work queue
   void* ws_stage = nullptr;        // float32 images between the two passes of a staged chain
   size_t ws_stage_bytes = 0;
   void* ws_mask = nullptr;         // labels and areas of the region masking

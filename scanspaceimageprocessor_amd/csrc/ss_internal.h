@@ -13,7 +13,8 @@ namespace ss {
 hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st);
 // Fused chain with the unsharp mask (stage 5): tile + halo recompute, separable blur in LDS.
 // Colour correction: none or the 3-term matrix only (callers run larger expansions as a pointwise pass first).
-// `ticket`: one uint32 of device memory owned by the caller; launches that share it must be stream-ordered
+// `ticket`: eight uint32 of device memory owned by the caller (the per-XCD segment counters); launches that share
+// them must be stream-ordered
 hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, uint32_t* ticket,
                       hipStream_t st);
 
