@@ -415,6 +415,30 @@ def test_bad_descriptors_are_rejected():
         run_chain_dev(img, sh=(1.0, 0.0, 7.0), lab_io=True, final_clip=True)
 
 
+def test_other_entry_points_reject_bad_arguments():
+    ctx = default_context()
+    buf = DeviceBuffer(ctx, 4096)
+    try:
+        with pytest.raises(_lib.ScanSpaceError) as e:
+            ctx.unpack_u16(buf.ptr + 2, buf.ptr, 16)            # source not 16-byte aligned
+        assert e.value.code == _lib.SS_ERR_INVALID
+        with pytest.raises(_lib.ScanSpaceError):
+            ctx.unpack_u16(0, buf.ptr, 16)
+        ctx.unpack_u16(buf.ptr, buf.ptr + 2048, 0)                # nothing to do is not an error
+        with pytest.raises(_lib.ScanSpaceError):
+            ctx.mask_regions(buf.ptr, 1, 70000, 1, 0.05, 0.98)    # columns are stored in 16 bits
+        with pytest.raises(_lib.ScanSpaceError):
+            ctx.mask_regions(buf.ptr, 4, 4, 1, float("nan"), 0.98)
+        with pytest.raises(_lib.ScanSpaceError):
+            ctx.resize_area(buf.ptr, 4, 4, 1, buf.ptr + 2048, 8, 8)   # area resampling only shrinks
+        with pytest.raises(_lib.ScanSpaceError):
+            ctx.negative_params(buf.ptr, 4, 4, 1, 0.5, 1.5, True, buf.ptr + 2048)   # fraction outside [0, 1]
+        ctx.sync()
+    finally:
+        buf.free()
+    assert ctx.pinned_empty((0, 3), np.float32).shape == (0, 3)
+
+
 # ---- re-entrancy: one context per worker thread (image_space.py:3483 runs N workers at once) --------
 
 
