@@ -132,6 +132,19 @@ def test_wide_rows_with_many_runs():
     check(from_mask(mask), min_area=1000)
 
 
+@pytest.mark.parametrize("seed", range(60))
+def test_random_masks_shapes_and_thresholds(seed):
+    rng = np.random.default_rng(7000 + seed)
+    h, w = int(rng.integers(1, 90)), int(rng.integers(1, 700))
+    density = float(rng.choice([0.05, 0.2, 0.45, 0.55, 0.8, 0.97]))
+    mask = rng.random((h, w)) < density
+    if rng.random() < 0.5:   # coarser structure: blocks of 3 x 5 pixels
+        mask = np.kron(rng.random((h // 3 + 1, w // 5 + 1)) < density, np.ones((3, 5), bool))[:h, :w]
+    b = int(rng.integers(1, 4))
+    imgs = np.stack([from_mask(np.roll(mask, i, axis=1), seed=seed + i) for i in range(b)])
+    check(imgs, min_area=int(rng.choice([1, 2, 7, 50, 200, 5000])))
+
+
 def test_area_threshold_and_limits_are_inclusive():
     mask = np.zeros((60, 60), bool)
     mask[2:12, 3:23] = True    # exactly 200
