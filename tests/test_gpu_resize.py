@@ -87,3 +87,19 @@ def test_uint16_decoder_output_gives_the_same_previews():
     small16 = raw16[:100, :150]
     np.testing.assert_array_equal(il.raw_preview(small16), as_float[:100, :150])
     np.testing.assert_array_equal(il.thumbnail_from_array(small16), as_float[:100, :150])
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shapes_and_scales(seed):
+    # scales below 2, between 2 and 16 (the strip kernels: 64 / 128 / 256 destination pixels per workgroup) and above,
+    # independent per axis, ragged sizes
+    rng = np.random.default_rng(9000 + seed)
+    h, w = int(rng.integers(1, 400)), int(rng.integers(1, 1200))
+    sx = float(rng.choice([1.0, 1.3, 2.0, 2.7, 4.0, 5.5, 8.0, 11.9, 16.0, 23.0]))
+    sy = float(rng.choice([1.0, 1.7, 3.0, 6.2, 9.0, 20.0]))
+    dsize = (max(1, int(w / sx)), max(1, int(h / sy)))
+    img = inputs.linear_image(seed, h, w)
+    got = il.resize_area(img, dsize)
+    want = orz.resize_area(img, dsize)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= TOL, (h, w, dsize)
