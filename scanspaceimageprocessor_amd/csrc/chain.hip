@@ -62,63 +62,68 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
   const uint32_t n_groups = n / G;
   constexpr uint32_t CHUNK = 256 * K;
 
+  // 16- and 8-bit outputs: one lane stores 12 bytes = G pixels, but loads them like the float path - lane t takes
+  // pixels t, t + 256, t + 512, t + 768 of a 1024-pixel chunk, so that every load covers whole cache lines across
+  // the wave and can stream - and the quantised values change lanes through LDS, laid out as the chunk's output
+  // bytes.
+  constexpr int BYTES = OutTraits<OUT>::BYTES;
+  constexpr int STAGE_WORDS = G == 1 ? 1 : 1024 * 3 * BYTES / 4;
+  __shared__ uint32_t stage[STAGE_WORDS];
+
   for (uint32_t base = blockIdx.x * CHUNK; base < n_groups; base += gridDim.x * CHUNK) {
     const ChainParams& P = params_now();
-    F3 in[K][G] = {};
+    F3 in[4] = {};
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const uint32_t g = base + k * 256 + threadIdx.x;
-      if (g < n_groups) {
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          // streaming loads only where one access covers whole cache lines across the wave (G = 1: lanes 12 bytes
-          // apart); with G > 1 a line is completed by several accesses and has to stay cached in between
-          if constexpr (G == 1) {
-            in[k][j] = load_stream(s + (g * G + j));
-          } else {
-            in[k][j] = s[g * G + j];
-          }
-        }
-      }
+    for (int k = 0; k < 4; ++k) {
+      // G == 1: group = pixel; G > 1: the chunk starts at pixel base * G
+      const uint32_t p = base * G + k * 256 + threadIdx.x;
+      if (p < (G == 1 ? n_groups : n)) in[k] = load_stream(s + p);
     }
-    // the K*G = 4 pixels of this lane go through the stages as two packed pairs (lanes past the end of the
-    // image compute on stale registers and store nothing)
-    Px flat[K * G];
+    // the 4 pixels of this lane go through the stages as two packed pairs (lanes past the end of the image
+    // compute on zeros and store nothing)
+    Px res[4];
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-      for (int j = 0; j < G; ++j) flat[k * G + j] = Px{in[k][j].x, in[k][j].y, in[k][j].z};
-    Px res[K * G];
-#pragma unroll
-    for (int q = 0; q < K * G; q += 2) {
-      const Px2 o2 = finish<OUT, false, v2f>(front<CCMC, SH, false, v2f>(pair_px(flat[q], flat[q + 1]), P, ip, M), P);
+    for (int q = 0; q < 4; q += 2) {
+      const Px2 o2 = finish<OUT, false, v2f>(
+          front<CCMC, SH, false, v2f>(pair_px(Px{in[q].x, in[q].y, in[q].z}, Px{in[q + 1].x, in[q + 1].y, in[q + 1].z}), P,
+                                      ip, M),
+          P);
       res[q] = px_lo(o2);
       res[q + 1] = px_hi(o2);
       // long term lists: one pair's arithmetic at a time keeps the register count down (282 -> 102 vector
       // registers for the 22-term lists, i.e. one wave per SIMD -> four)
       if constexpr (ccm_needs_table<CCMC>) __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (G == 1) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const uint32_t g = base + k * 256 + threadIdx.x;
-      if (g < n_groups) {
-        const Px* o = res + k * G;
-        if constexpr (G == 1) {
-          store_stream(reinterpret_cast<F3*>(d) + g, F3{o[0].r, o[0].g, o[0].b});
-        } else if constexpr (G == 2) {
-          U3 q;
-          q.x = quant16(o[0].r) | (quant16(o[0].g) << 16);
-          q.y = quant16(o[0].b) | (quant16(o[1].r) << 16);
-          q.z = quant16(o[1].g) | (quant16(o[1].b) << 16);
-          store_stream(reinterpret_cast<U3*>(d) + g, q);
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t g = base + k * 256 + threadIdx.x;
+        if (g < n_groups) store_stream(reinterpret_cast<F3*>(d) + g, F3{res[k].r, res[k].g, res[k].b});
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t i = k * 256 + threadIdx.x;  // pixel inside the chunk
+        if constexpr (BYTES == 2) {
+          uint16_t* h = reinterpret_cast<uint16_t*>(stage) + 3 * i;
+          h[0] = (uint16_t)quant16(res[k].r);
+          h[1] = (uint16_t)quant16(res[k].g);
+          h[2] = (uint16_t)quant16(res[k].b);
         } else {
-          U3 q;
-          q.x = quant8(o[0].r) | (quant8(o[0].g) << 8) | (quant8(o[0].b) << 16) | (quant8(o[1].r) << 24);
-          q.y = quant8(o[1].g) | (quant8(o[1].b) << 8) | (quant8(o[2].r) << 16) | (quant8(o[2].g) << 24);
-          q.z = quant8(o[2].b) | (quant8(o[3].r) << 8) | (quant8(o[3].g) << 16) | (quant8(o[3].b) << 24);
-          store_stream(reinterpret_cast<U3*>(d) + g, q);
+          uint8_t* b = reinterpret_cast<uint8_t*>(stage) + 3 * i;
+          b[0] = (uint8_t)quant8(res[k].r);
+          b[1] = (uint8_t)quant8(res[k].g);
+          b[2] = (uint8_t)quant8(res[k].b);
         }
       }
+      __syncthreads();
+      constexpr uint32_t UNITS = 1024 * 3 * BYTES / 12;  // 12-byte units of the chunk = groups
+#pragma unroll
+      for (uint32_t u = threadIdx.x; u < UNITS; u += 256) {
+        const uint32_t g = base + u;
+        if (g < n_groups) store_stream(reinterpret_cast<U3*>(d) + g, U3{stage[3 * u], stage[3 * u + 1], stage[3 * u + 2]});
+      }
+      __syncthreads();  // the next trip writes the staging words again
     }
   }
   // the n % G pixels no full group covers
