@@ -1,10 +1,11 @@
 // Pointwise fused correction-chain kernel for gfx950.
 //
-//   chain_kernel : stages 1-4, 6, 7 as one pointwise pass.  One lane owns G adjacent pixels so
-//                  that every lane stores exactly 12 bytes (one global_store_dwordx3, lanes
-//                  contiguous): G = 1 for float32, 2 for uint16, 4 for uint8 output.  Loads are
-//                  per-pixel global_load_dwordx3 (12 B, 4-byte aligned, no width restriction).
-//                  Algorithmic traffic: 12 B/px in + 12 / 6 / 3 B/px out; HBM-bound.
+//   chain_kernel : stages 1-4, 6, 7 as one pointwise pass.  A lane loads 4 pixels, 256 pixels apart
+//                  (per-pixel global_load_dwordx3: 12 B, 4-byte aligned, lanes contiguous, no width
+//                  restriction), and every lane stores exactly 12 bytes (one global_store_dwordx3,
+//                  lanes contiguous): 1 pixel of float32, or G = 2 pixels of uint16 / 4 pixels of uint8
+//                  whose quantised values reach their storing lane through LDS.  Loads and stores
+//                  stream (nontemporal).  Algorithmic traffic: 12 B/px in + 12 / 6 / 3 B/px out; HBM-bound.
 
 #include "ss_internal.h"
 
