@@ -130,6 +130,10 @@ class ImageCorrectionWorker:
         # host-side hooks (defaults look the libraries up when first needed)
         self.raw_loader = None     # callable(path) -> (H,W,3) float32 in [0,1]
         self.image_writer = None   # callable(path, array, fmt)
+        # True: `process_array` returns views of two page-locked arrays that the thread's context keeps and
+        # overwrites with the next image (no allocation, no staging copy: 11 -> 7 ms per 24 MP image).  For
+        # headless runs whose writer and preview consumer are done with an image before the next one starts.
+        self.reuse_output_buffers = False
         self._ccm = None
 
     def cancel(self):
@@ -265,7 +269,12 @@ class ImageCorrectionWorker:
             ctx.negative_params(src, h, w, 1, self.negative_low_pct, self.negative_high_pct,
                                 editingTools.NUMPY_LEGACY_PERCENTILE, neg)
             kw.update(neg=True, neg_params_dev=neg)
-        encoded = np.empty((h, w, 3), dtype=_lib.OUT_DTYPES[kind])
+        def host_array(tag, dtype):
+            if self.reuse_output_buffers:
+                return ctx.host_workspace(tag, (h, w, 3), dtype)
+            return np.empty((h, w, 3), dtype=dtype)
+
+        encoded = host_array("worker.encoded", _lib.OUT_DTYPES[kind])
         if getattr(self, "export_masked", False):
             # reference order (imageProcessorWorker.py:902-912): chain -> _apply_masking -> encode.  The chain
             # leaves the clipped linear image in `dst`, the masking zeroes regions in place, and the encode
@@ -277,7 +286,7 @@ class ImageCorrectionWorker:
             if encoded.dtype == np.uint8:
                 preview = encoded
             else:
-                preview = np.empty((h, w, 3), dtype=np.uint8)
+                preview = host_array("worker.preview", np.uint8)
                 ctx.chain_run(make_desc(h, w, 1, out="u8_linear"), dst, src)
                 ctx.download(preview, src)
             return encoded, preview
@@ -286,7 +295,7 @@ class ImageCorrectionWorker:
         if encoded.dtype == np.uint8:
             preview = encoded
         else:
-            preview = np.empty(img.shape, dtype=np.uint8)
+            preview = host_array("worker.preview", np.uint8)
             ctx.chain_run(make_desc(h, w, 1, out="u8_linear", **kw), src, dst)
             ctx.download(preview, dst)
         return encoded, preview

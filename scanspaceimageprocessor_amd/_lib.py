@@ -165,6 +165,7 @@ class Context:
             for ptr, _ in getattr(self, "_workspaces", {}).values():
                 self.lib.ss_free(self.handle, C.c_void_p(ptr))
             self._workspaces = {}
+            self.__dict__.pop("_host_workspaces", None)  # (freed by their finalizers)
             self.lib.ss_ctx_destroy(self.handle)
             self.handle = None
 
@@ -243,6 +244,17 @@ class Context:
 
         weakref.finalize(buf, release)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def host_workspace(self, tag, shape, dtype=np.float32):
+        """A page-locked array kept under ``tag`` for as long as the context lives and handed out again on the
+        next request (grown when too small): the caller must be done with it before asking again."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        pool = self.__dict__.setdefault("_host_workspaces", {})
+        have = pool.get(tag)
+        if have is None or have.nbytes < nbytes:
+            have = pool[tag] = self.pinned_empty((max(nbytes, 1),), np.uint8)
+        return have[:nbytes].view(dtype).reshape(shape)
 
     def upload(self, dst_dev, arr):
         arr = np.ascontiguousarray(arr)

@@ -221,3 +221,25 @@ def test_saved_job_runs_end_to_end(tmp_path):
     want = oc.encode_image(oc.worker_chart_path(img, M_T, M_R, exposure_adj=0.25), ".tiff", 16)
     got = iw.read_tiff(out_path)
     assert np.max(np.abs(got.astype(np.int64) - want.astype(np.int64))) <= 1
+
+
+def test_reused_output_buffers_give_the_same_images():
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    imgs = [inputs.linear_image(40 + i, 70, 110) for i in range(3)]
+    plain = ipw.ImageCorrectionWorker([], M_T, "/tmp", None, output_format=".tiff", tiff_bitdepth=16)
+    pooled = ipw.ImageCorrectionWorker([], M_T, "/tmp", None, output_format=".tiff", tiff_bitdepth=16)
+    pooled.reuse_output_buffers = True
+    seen = set()
+    for img in imgs:
+        e0, p0 = plain.process_array(img, "a.nef")
+        e1, p1 = pooled.process_array(img, "a.nef")
+        np.testing.assert_array_equal(e0, e1)
+        np.testing.assert_array_equal(p0, p1)
+        seen.add(e1.__array_interface__["data"][0])
+    assert len(seen) == 1      # the same page-locked memory every time
+    big = inputs.linear_image(50, 90, 130)   # a larger image grows the buffers
+    e1, p1 = pooled.process_array(big, "a.nef")
+    e0, p0 = plain.process_array(big, "a.nef")
+    np.testing.assert_array_equal(e0, e1)
+    np.testing.assert_array_equal(p0, p1)

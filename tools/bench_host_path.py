@@ -55,6 +55,8 @@ for fmt, depth, masked in ((".tiff", 16, False), (".jpg", 8, False), (".tiff", 1
            lambda: w.process_array(img, "a.nef"))
     if not masked:
         timeit(f"  the same from the decoder's uint16 image", lambda: w.process_array(raw16, "a.nef"))
+        w.reuse_output_buffers = True
+        timeit(f"  ... into reused page-locked output buffers", lambda: w.process_array(raw16, "a.nef"))
 
 # The reference runs several images at once, one worker thread each (4 by default, image_space.py:238): one context
 # (own stream, own staging buffers) per thread, so one thread's upload overlaps another's download and kernels.
