@@ -675,6 +675,9 @@ static hipError_t launch_usm_ccm(const ChainParams& P, int batch, int out_kind, 
   if (lin3) return launch_usm_out<R_T, CCM_LIN3, false>(P, batch, out_kind, src, dst, ticket, st);
   // colour corrections with more terms run as a pointwise pass of their own in front (see ss_chain_run)
   if (P.ccm_kind != SS_CCM_NONE) return hipErrorInvalidValue;
+  // the worker's no-chart path with exposure and sharpen only (and the second pass of a staged chain)
+  const bool plain_none = !P.neg && P.n_gain == 1 && !P.sh && !P.lab_io && P.usm_thr == 0.0f;
+  if (plain_none) return launch_usm_out<R_T, CCM_NONE, true>(P, batch, out_kind, src, dst, ticket, st);
   return launch_usm_out<R_T, CCM_NONE, false>(P, batch, out_kind, src, dst, ticket, st);
 }
 

@@ -65,7 +65,7 @@ def main():
 
     todo = args.configs.split(",")
     H, W, B = 4000, 6000, args.batch
-    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "1c", "5", "5b", "5c", "t", "m")):
+    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "1c", "5", "5p", "5b", "5c", "t", "m")):
         img = images(H, W, B)
         out = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
     if "1" in todo:
@@ -86,6 +86,9 @@ def main():
     if "2r1" in todo:
         d = make_desc(H, W, B, ccm=lin3, gains=[1.1], usm=(50.0, 1.0, 0.0), final_clip=True, out="u16")
         report("2r1 ccm3+gain+usm(r1,a50)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "5p" in todo:  # the worker's no-chart path with exposure and sharpen only
+        d = make_desc(H, W, B, gains=[1.2], usm=(40.0, 1.0, 0.0), final_clip=True, out="u16")
+        report("5p gain+usm(r1,a40)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
     if "5" in todo:  # the worker's no-chart path with every adjustment on: exposure, S/H, sharpen radius 1
         d = make_desc(H, W, B, gains=[1.2], sh=(0.5 / 70, -0.5 * 1.3, 7.0), usm=(40.0, 1.0, 0.0), final_clip=True, out="u16")
         report("5  gain+S/H+usm(r1,a40)+u16", H, W, B, 18, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
