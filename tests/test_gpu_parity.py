@@ -284,6 +284,22 @@ def test_usm_all_radii_f32(radius, threshold):
     assert np.max(np.abs(got - want)) <= F32_TOL
 
 
+@pytest.mark.parametrize("radius", [1.0, 2.0, 2.5])
+@pytest.mark.parametrize("out", ["f32", "u16", "u8"])
+def test_exposure_and_sharpen_without_a_chart(radius, out):
+    """The worker's no-chart path with exposure and sharpen only (its own kernel specialisation)."""
+    imgs = np.stack([inputs.linear_image(88 + i, 97, 301) for i in range(2)])
+    got = run_chain_dev(imgs, gains=[2.0 ** 0.4], usm=(35.0, radius, 0.0), final_clip=True, out=out)
+    for i in range(2):
+        c = np.clip(oc.adjust_sharpen(np.clip(imgs[i].astype(np.float64) * 2.0 ** 0.4, 0, 1), 35.0, radius, 0.0), 0, 1)
+        if out == "f32":
+            assert np.max(np.abs(got[i] - c)) <= F32_TOL
+        else:
+            scale = 65535.0 if out == "u16" else 255.0
+            want = np.clip(lv.eotf_inverse_sRGB(c) * scale, 0, scale).astype(got.dtype)
+            assert np.max(np.abs(got[i].astype(np.int64) - want.astype(np.int64))) <= 1
+
+
 def test_usm_of_constant_image_is_identity_after_round_trip():
     img = np.full((70, 140, 3), 0.5, np.float32)
     got = run_chain_dev(img, usm=(80.0, 2.0, 0.0), out="f32")[0]
