@@ -64,8 +64,16 @@ MATRIX_sRGB_TO_XYZ = np.array(
     [[0.4124, 0.3576, 0.1805], [0.2126, 0.7152, 0.0722], [0.0193, 0.1192, 0.9505]],
     dtype=np.float64,
 )
-# colour derives the inverse numerically; it does not use the rounded table.
-MATRIX_XYZ_TO_sRGB = np.linalg.inv(MATRIX_sRGB_TO_XYZ)
+# IEC 61966-2-1:1999 gives BOTH matrices to four decimals and colour's sRGB colourspace carries both as given
+# (``use_derived_matrix_XYZ_to_RGB`` is off by default), so the pair is not an exact inverse pair:
+# XYZ_TO_sRGB . sRGB_TO_XYZ differs from the identity by up to 4e-5.  Pinned by colour's own docstring
+# example, which only this table reproduces (tests/test_oracle_leaves.py):
+#   XYZ_to_sRGB([0.20654008, 0.12197225, 0.05136952]) -> [0.70573936, 0.19248266, 0.22354169]
+# (the numerical inverse gives [0.70574132, 0.19244650, 0.22353975]).
+MATRIX_XYZ_TO_sRGB = np.array(
+    [[3.2406, -1.5372, -0.4986], [-0.9689, 1.8758, 0.0415], [0.0557, -0.2040, 1.0570]],
+    dtype=np.float64,
+)
 
 D65_xy = (0.3127, 0.3290)
 

@@ -51,28 +51,30 @@ struct ChainParams {
   float ccm_full[SS_MAX_CCM_TERMS][4];
 };
 
-// sRGB <-> XYZ of colour-science's sRGB colourspace (the published 4-digit matrix and its numerical inverse),
-// folded with the D65 white (xy = 0.3127, 0.3290) of XYZ_to_Lab / Lab_to_XYZ: `fwd` rows are divided by the
-// white, `inv` columns multiplied by it.  Compile-time constants: as kernel arguments they (and the register
-// pairs packed arithmetic wants for them) crowded the scalar register file.
+// sRGB <-> XYZ of colour-science's sRGB colourspace: IEC 61966-2-1:1999 gives both matrices to four decimals
+// and colour carries both as given, so they are not an exact inverse pair (XYZ->RGB . RGB->XYZ = I + E with
+// |E| up to 4e-5: a pixel that goes through _rgb_to_lab and _lab_to_rgb unedited comes back as (I + E) . rgb).
+// Folded with the D65 white (xy = 0.3127, 0.3290) of XYZ_to_Lab / Lab_to_XYZ: `fwd` rows are divided by the
+// white, `inv` columns multiplied by it; `drift` = E.  Compile-time constants: as kernel arguments they (and
+// the register pairs packed arithmetic wants for them) crowded the scalar register file.
 struct LabMatrices {
   float fwd[9];
   float inv[9];
+  float drift[9];
 };
 
 constexpr LabMatrices make_lab_matrices() {
   const double m[9] = {0.4124, 0.3576, 0.1805, 0.2126, 0.7152, 0.0722, 0.0193, 0.1192, 0.9505};
-  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-  const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
-                         (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
-                         (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  const double inv[9] = {3.2406, -1.5372, -0.4986, -0.9689, 1.8758, 0.0415, 0.0557, -0.2040, 1.0570};
   const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
   LabMatrices o{};
   for (int r = 0; r < 3; ++r)
     for (int k = 0; k < 3; ++k) {
       o.fwd[r * 3 + k] = (float)(m[r * 3 + k] / white[r]);
       o.inv[r * 3 + k] = (float)(inv[r * 3 + k] * white[k]);
+      double rt = 0.0;
+      for (int j = 0; j < 3; ++j) rt += inv[r * 3 + j] * m[j * 3 + k];
+      o.drift[r * 3 + k] = (float)(rt - (r == k ? 1.0 : 0.0));
     }
   return o;
 }
@@ -215,8 +217,9 @@ __device__ __forceinline__ PxT<V> lab_to_rgb(const LabT<V> q, const ChainParams&
 // unedited pixel comes back exactly.  In float32 the literal round trip loses ~1e-7 absolute per linear
 // channel (X, Y, Z ~ 0.5 cancel to a dark channel through the inverse matrix), which two successive sRGB
 // encodes amplify 167-fold near black - several 16-bit steps.  So the edit is applied as a difference:
-//   linear' = linear + M_inv * (g(f + df) - g(f)),   g = lab_finv,  f = (fx, fy, fz) of the pixel,
-// whose error is proportional to the size of the edit, not to the size of XYZ.
+//   linear' = (I + E) linear + M_inv * (g(f + df) - g(f)),   g = lab_finv,  f = (fx, fy, fz) of the pixel,
+// whose error is proportional to the size of the edit, not to the size of XYZ.  (E: see LabMatrices; the
+// reference's own unedited round trip is (I + E) linear in exact arithmetic.)
 
 template <class V>
 struct LabFT {
@@ -261,10 +264,14 @@ __device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V
                                                  const V dfz) {
   // (a wave-uniform shortcut for "every pixel on the cubic segment" costs as much to decide as it saves)
   const V dx = finv_delta_any(f.fx, dfx), dy = finv_delta_any(f.fy, dfy), dz = finv_delta_any(f.fz, dfz);
+  // the unedited part of the round trip: (I + E) . linear, E = the mismatch of the two IEC matrices
+  const V ur = mad<V>(kLab.drift[0], lin.r, mad<V>(kLab.drift[1], lin.g, mad<V>(kLab.drift[2], lin.b, lin.r)));
+  const V ug = mad<V>(kLab.drift[3], lin.r, mad<V>(kLab.drift[4], lin.g, mad<V>(kLab.drift[5], lin.b, lin.g)));
+  const V ub = mad<V>(kLab.drift[6], lin.r, mad<V>(kLab.drift[7], lin.g, mad<V>(kLab.drift[8], lin.b, lin.b)));
   PxT<V> o;
-  o.r = mad<V>(kLab.inv[0], dx, mad<V>(kLab.inv[1], dy, mad<V>(kLab.inv[2], dz, lin.r)));
-  o.g = mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, lin.g)));
-  o.b = mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, lin.b)));
+  o.r = mad<V>(kLab.inv[0], dx, mad<V>(kLab.inv[1], dy, mad<V>(kLab.inv[2], dz, ur)));
+  o.g = mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, ug)));
+  o.b = mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, ub)));
   return o;
 }
 

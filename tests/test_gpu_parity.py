@@ -300,10 +300,14 @@ def test_exposure_and_sharpen_without_a_chart(radius, out):
             assert np.max(np.abs(got[i].astype(np.int64) - want.astype(np.int64))) <= 1
 
 
-def test_usm_of_constant_image_is_identity_after_round_trip():
+def test_usm_of_constant_image_is_the_bare_round_trip():
     img = np.full((70, 140, 3), 0.5, np.float32)
     got = run_chain_dev(img, usm=(80.0, 2.0, 0.0), out="f32")[0]
-    assert np.max(np.abs(got - 0.5)) <= 2e-6
+    # nothing to sharpen: what is left is the reference's own round trip sRGB -> Lab -> sRGB, which is not the
+    # identity (the two IEC sRGB matrices are rounded independently): about 1e-5 on mid grey
+    want = oc.adjust_sharpen(img, 80.0, 2.0, 0.0)
+    assert 3e-6 < np.max(np.abs(want - 0.5)) < 3e-5
+    assert np.max(np.abs(got - want)) <= 2e-6
 
 
 @pytest.mark.parametrize("stage_bytes", [None, 1, 2 * 150 * 220 * 12])
