@@ -17,7 +17,9 @@ Parity status
   CCTFs, sRGB<->XYZ<->Lab; OpenCV 4.x ``GaussianBlur``) are restated from
   their published definitions because neither package is installed here and
   the reference ships no tests or fixtures:  PARITY UNPINNED at the leaves.
-  They are guarded by analytic known-answer tests only.
+  They are guarded by known-answer tests: analytic identities, published
+  tables, and the worked examples of colour-science's own docstrings
+  (tests/test_oracle_leaves.py).
 """
 
 from . import leaves, chain  # noqa: F401

@@ -14,7 +14,8 @@ vendored under /root/reference and are not installed in this image:
 Every function below restates the *published* algorithm of the named leaf in
 plain numpy float64.  PARITY UNPINNED: the reference holds no test, golden
 vector or fixture for any of them, so the constants here are specification,
-checked only by the analytic known-answer tests in tests/test_oracle_leaves.py.
+checked by the known-answer tests in tests/test_oracle_leaves.py (analytic
+identities, published tables, the worked examples of colour-science's docstrings).
 """
 
 from __future__ import annotations

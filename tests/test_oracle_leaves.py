@@ -135,6 +135,15 @@ def test_gaussian_kernel_properties():
     assert lv.gaussian_kernel_f32(7, 1.0)[3] == np.float32(1.0 / np.exp(-i * i / 2.0).sum())
 
 
+def test_gaussian_taps_and_cheung_terms_against_published_values():
+    # cv2.getGaussianKernel(7, 1.0) and (5, 1.0) as commonly printed (8 digits)
+    np.testing.assert_allclose(lv.gaussian_kernel_f32(7, 1.0)[:4], [0.00443305, 0.05400558, 0.24203623, 0.39905028], atol=2e-8)
+    np.testing.assert_allclose(lv.gaussian_kernel_f32(5, 1.0)[:3], [0.05448868, 0.24420134, 0.40261996], atol=2e-8)
+    # colour.characterisation.matrix_augmented_Cheung2004's docstring example (terms=5)
+    np.testing.assert_allclose(lv.expand(np.array([[0.1722481, 0.0917066, 0.06416938]]), "Cheung 2004", terms=5)[0],
+                               [0.1722481, 0.0917066, 0.06416938, 0.00101364, 1.0], atol=5e-9)
+
+
 def test_blur_constant_and_border_against_scipy():
     const = np.full((20, 30), 0.37, dtype=np.float32)
     np.testing.assert_allclose(lv.gaussian_blur_reflect(const, 13, 2.0), const, atol=2e-7)
