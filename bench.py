@@ -257,7 +257,7 @@ def main():
                 "traffic_note": ("bytes per launch = 24.0 B/px" if config5 else "bytes per launch = 18.88 B/px")
                                 + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) x px_per_launch",
                 "limiter": ("HBM streaming" if config5 else
-                            "vector ALU, not HBM: 196 VALU instructions per pixel (25 of them log2/exp2), VALU busy 93.5 % "
+                            "vector ALU, not HBM: 201 VALU instructions per pixel (25 of them log2/exp2), VALU busy 93.5 % "
                             "of the kernel's cycles (rocprofv3 SQ counters, profiles/r01_usm_pmc.md)"),
                 "algorithmic_bytes_per_px": algo_bytes,
                 "px_per_launch": px_per_launch, "kernel_ms": round(kernel_ms, 4),
