@@ -74,7 +74,8 @@ constexpr LabMatrices make_lab_matrices() {
       o.inv[r * 3 + k] = (float)(inv[r * 3 + k] * white[k]);
       double rt = 0.0;
       for (int j = 0; j < 3; ++j) rt += inv[r * 3 + j] * m[j * 3 + k];
-      o.drift[r * 3 + k] = (float)(rt - (r == k ? 1.0 : 0.0));
+      const double e = rt - (r == k ? 1.0 : 0.0);
+      o.drift[r * 3 + k] = (e < 1e-12 && e > -1e-12) ? 0.0f : (float)e;  // (one entry is 0 in decimal arithmetic)
     }
   return o;
 }
