@@ -127,30 +127,29 @@ def adjust_sharpen(image: np.ndarray, amount: float = 0.0, radius: float = 1.0, 
 # ---------------------------------------------------------------------------------------------
 
 
-def _cct_to_xy_kang2002(cct: float):
-    """colour.temperature.CCT_to_xy default method (Kang et al. 2002), valid 1667 K .. 25000 K."""
+def _cct_to_xy_cie_d(cct: float):
+    """``colour.temperature.CCT_to_xy`` with its default method, "CIE Illuminant D Series" (the daylight locus;
+    colour evaluates it outside 4000 K .. 25000 K too, with a usage warning only).  Its docstring example:
+    6504.38938305 K -> (0.3127077, 0.3291128)."""
     T = float(cct)
-    if T <= 4000:
-        x = -0.2661239e9 / T ** 3 - 0.2343589e6 / T ** 2 + 0.8776956e3 / T + 0.179910
+    if T <= 7000:
+        x = -4.607 * 10 ** 9 / T ** 3 + 2.9678 * 10 ** 6 / T ** 2 + 0.09911 * 10 ** 3 / T + 0.244063
     else:
-        x = -3.0258469e9 / T ** 3 + 2.1070379e6 / T ** 2 + 0.2226347e3 / T + 0.24039
-    if T <= 2222:
-        y = -1.1063814 * x ** 3 - 1.34811020 * x ** 2 + 2.18555832 * x - 0.20219683
-    elif T <= 4000:
-        y = -0.9549476 * x ** 3 - 1.37418593 * x ** 2 + 2.09137015 * x - 0.16748867
-    else:
-        y = 3.0817580 * x ** 3 - 5.8733867 * x ** 2 + 3.75112997 * x - 0.37001483
+        x = -2.0064 * 10 ** 9 / T ** 3 + 1.9018 * 10 ** 6 / T ** 2 + 0.24748 * 10 ** 3 / T + 0.23704
+    y = -3.000 * x ** 2 + 2.870 * x - 0.275
     return x, y
 
 
-_M_XYZ_TO_SRGB = np.linalg.inv(np.array([[0.4124, 0.3576, 0.1805], [0.2126, 0.7152, 0.0722], [0.0193, 0.1192, 0.9505]]))
+# ``colour.XYZ_to_RGB(XYZ, RGB_COLOURSPACES['sRGB'], apply_cctf_encoding=False)``: no chromatic adaptation without an
+# illuminant argument, and the colourspace's own XYZ -> RGB matrix, which is the IEC 61966-2-1 four-decimal table
+_M_XYZ_TO_SRGB = np.array([[3.2406, -1.5372, -0.4986], [-0.9689, 1.8758, 0.0415], [0.0557, -0.2040, 1.0570]])
 
 
 def calculate_white_balance_multipliers(current_temp: float, target_temp: float, tint: float = 0.0):
     """RGB multipliers from two colour temperatures (reference editingTools.py:547-602).  Host arithmetic."""
 
     def rgb_of(cct):
-        x, y = _cct_to_xy_kang2002(cct)
+        x, y = _cct_to_xy_cie_d(cct)
         XYZ = np.array([x / y, 1.0, (1.0 - x - y) / y])
         return _M_XYZ_TO_SRGB @ XYZ
 

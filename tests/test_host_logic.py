@@ -129,8 +129,15 @@ def test_white_balance_multipliers_known_answers():
     assert min(warm) == pytest.approx(1.0) and warm[0] > warm[1] > warm[2]
     tint = et.calculate_white_balance_multipliers(5500, 5500, 50.0)
     assert tint[1] / tint[0] == pytest.approx(1.05)
-    x, y = et._cct_to_xy_kang2002(6500.0)  # Planckian locus at 6500 K is (0.3135, 0.3237)
-    assert abs(x - 0.3135) < 5e-4 and abs(y - 0.3237) < 5e-4
+    # colour.temperature.CCT_to_xy_CIE_D's docstring example (the default method of CCT_to_xy)
+    x, y = et._cct_to_xy_cie_d(6504.38938305)
+    assert (x, y) == pytest.approx((0.3127077, 0.3291128), abs=1e-7)   # digits printed there, truncated
+    # D65 maps to (almost) equal sRGB channels: from 6504 K to 6504 K nothing changes, from there to 5000 K
+    # (0.3457, 0.3587 on the daylight locus) red gains on blue
+    x5, y5 = et._cct_to_xy_cie_d(5000.0)
+    assert abs(x5 - 0.3457) < 2e-4 and abs(y5 - 0.3587) < 2e-4
+    m = et.calculate_white_balance_multipliers(6504.38938305, 5000.0)
+    assert m[2] == pytest.approx(1.0) and m[0] > m[1] > 1.0
 
 
 def test_adjustment_stage_translation_keeps_reference_prescaling_and_order():
