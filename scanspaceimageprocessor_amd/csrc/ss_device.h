@@ -215,7 +215,7 @@ __device__ __forceinline__ PxT<V> lab_to_rgb(const LabT<V> q, const ChainParams&
 
 // ---- Lab edits on RGB data without the round-trip error -----------------------------------------
 // The reference edits L (and scales a, b) between _rgb_to_lab and _lab_to_rgb in float64, where an
-// unedited pixel comes back exactly.  In float32 the literal round trip loses ~1e-7 absolute per linear
+// unedited pixel comes back as (I + E) rgb to 1e-16.  In float32 the literal round trip loses ~1e-7 absolute per linear
 // channel (X, Y, Z ~ 0.5 cancel to a dark channel through the inverse matrix), which two successive sRGB
 // encodes amplify 167-fold near black - several 16-bit steps.  So the edit is applied as a difference:
 //   linear' = (I + E) linear + M_inv * (g(f + df) - g(f)),   g = lab_finv,  f = (fx, fy, fz) of the pixel,
