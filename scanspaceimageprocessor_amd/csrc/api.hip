@@ -164,6 +164,8 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
   P->usm = (d->usm_enabled && d->usm_amount > 0.0f) ? 1 : 0;
   if (P->usm) {
     if (!(d->usm_radius > 0.0f)) return fail(c, SS_ERR_INVALID, "usm_radius (sigma) must be positive");
+    if (!(d->usm_radius < 1.0e6f))  // (also keeps the float -> int conversion below defined)
+      return fail(c, SS_ERR_UNSUPPORTED, "usm_radius %g is beyond any supported kernel size", (double)d->usm_radius);
     const int k = usm_kernel_size(d->usm_radius);
     const int r = k / 2;
     if (r < 1 || r > SS_MAX_USM_RADIUS)

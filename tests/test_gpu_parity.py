@@ -431,6 +431,9 @@ def test_bad_descriptors_are_rejected():
     assert e.value.code == _lib.SS_ERR_INVALID
     with pytest.raises(_lib.ScanSpaceError):
         run_chain_dev(img, usm=(10.0, 9.0, 0.0))  # 55-tap kernel: unsupported
+    for radius in (float("inf"), float("nan"), 3.0e9, -1.0):
+        with pytest.raises(_lib.ScanSpaceError):
+            run_chain_dev(img, usm=(10.0, radius, 0.0))
     with pytest.raises(_lib.ScanSpaceError):
         run_chain_dev(img, sh=(1.0, 0.0, 7.0), lab_io=True, final_clip=True)
 
