@@ -42,10 +42,11 @@ def _default_reference_swatches():
         from colour import RGB_COLOURSPACES  # type: ignore
     except Exception:
         return None
-    reference = colour.CCS_COLOURCHECKERS['ColorChecker24 - After November 2014']
-    return colour.XYZ_to_RGB(
-        colour.xyY_to_XYZ(list(reference.data.values())), RGB_COLOURSPACES['sRGB'],
-        illuminant=reference.illuminant, chromatic_adaptation_transform="CAT02", apply_cctf_encoding=False)
+    chart = colour.CCS_COLOURCHECKERS['ColorChecker24 - After November 2014']
+    patches_xyz = colour.xyY_to_XYZ(np.array([xyY for xyY in chart.data.values()], dtype=np.float64))
+    linear_srgb = colour.XYZ_to_RGB(patches_xyz, RGB_COLOURSPACES['sRGB'], illuminant=chart.illuminant,
+                                    chromatic_adaptation_transform="CAT02", apply_cctf_encoding=False)
+    return np.asarray(linear_srgb, dtype=np.float64)
 
 
 reference_swatches = _default_reference_swatches()
