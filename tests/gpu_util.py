@@ -1,6 +1,8 @@
 """Helpers for the -m gpu parity tests: everything goes through the C ABI (ctypes)."""
 
 
+import os
+
 import numpy as np
 
 from scanspaceimageprocessor_amd import _lib, default_context
@@ -54,3 +56,11 @@ def run_chain_dev(images, **kw):
 
 def fit(M_T, M_R, **kw):
     return matrix_colour_correction(M_T, M_R, **kw)
+
+
+def fuzz_seeds(default_count):
+    """Seeds of a randomised test: ``default_count`` of them from 0, or the range the environment asks for
+    (SS_FUZZ_FIRST, SS_FUZZ_COUNT) when a longer soak run is wanted."""
+    first = int(os.environ.get("SS_FUZZ_FIRST", "0"))
+    count = int(os.environ.get("SS_FUZZ_COUNT", str(default_count)))
+    return range(first, first + count)

@@ -4,7 +4,7 @@ oracle/masking.py.  The zeroed pixel set and its size must match exactly."""
 import numpy as np
 import pytest
 
-from gpu_util import DeviceBuffer
+from gpu_util import DeviceBuffer, fuzz_seeds
 from oracle import inputs
 from oracle import masking as om
 from scanspaceimageprocessor_amd import default_context
@@ -132,7 +132,7 @@ def test_wide_rows_with_many_runs():
     check(from_mask(mask), min_area=1000)
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", fuzz_seeds(60))
 def test_random_masks_shapes_and_thresholds(seed):
     rng = np.random.default_rng(7000 + seed)
     h, w = int(rng.integers(1, 90)), int(rng.integers(1, 700))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_input
-from gpu_util import DeviceBuffer, fit, run_chain_dev
+from gpu_util import DeviceBuffer, fit, fuzz_seeds, run_chain_dev
 from scanspaceimageprocessor_amd.chain import make_desc
 from oracle import chain as oc
 from oracle import inputs
@@ -526,9 +526,8 @@ def _oracle_chain(img, M_T, M_R, neg, ccm_kw, gains, sh, usm, final_clip, out):
     return np.clip(enc * scale, 0, scale).astype(np.uint16 if out == "u16" else np.uint8)
 
 
-@pytest.mark.parametrize("seed", range(200))
-def test_random_stage_combinations(swatches, seed):
-    M_T, M_R = swatches
+def fuzz_case(seed, M_T, M_R):
+    """One random descriptor: returns (imgs, kw, ingredients of the oracle chain)."""
     rng = np.random.default_rng(1000 + seed)
     h, w = int(rng.integers(1, 70)), int(rng.integers(1, 300))
     b = int(rng.integers(1, 3))
@@ -557,8 +556,10 @@ def test_random_stage_combinations(swatches, seed):
     final_clip = bool(rng.random() < 0.7) or sh is not None or usm is not None
     out = ["f32", "f32_srgb", "u16", "u8"][int(rng.integers(0, 4))]
     high_order = ccm_kw is not None and (ccm_kw.get("terms", 3) > 8 or ccm_kw.get("degree", 1) >= 3)
-    if high_order and out in ("u16", "u8"):
-        out = "f32"  # their float32 error is a multiple of the 1e-5 bar (sum of |coefficient * term|), see the term tests
+    if high_order and out != "f32":
+        # their float32 error is a multiple of the 1e-5 bar (sum of |coefficient * term|, see the term tests), and
+        # the sRGB encode multiplies it by up to 12.92 in a dark channel
+        out = "f32"
     if out != "f32" and not final_clip and ccm_kw is not None:
         final_clip = True  # encoded outputs of unclipped data are not a reference path
     kw = dict(gains=gains, final_clip=final_clip, out=out)
@@ -570,23 +571,55 @@ def test_random_stage_combinations(swatches, seed):
         kw["sh"] = sh
     if usm is not None:
         kw["usm"] = usm
+    return imgs, kw, (neg, ccm_kw, gains, sh, usm, final_clip, out)
+
+
+LAB_EDIT_ERR = 3.0e-7  # float32 evaluation error of one Lab edit, absolute, in the linear light it returns
+
+
+def _encode_slope(x):
+    """d/dx of the sRGB encode (IEC 61966-2-1) at linear x."""
+    x = np.maximum(np.asarray(x, np.float64), 1e-12)
+    return np.where(x <= 0.0031308, 12.92, (1.055 / 2.4) * x ** (1.0 / 2.4 - 1.0))
+
+
+def _lab_edit_allowance(v, n_edits, output_encoded):
+    """What the float32 evaluation of `n_edits` Lab edits may add to the error of the final value `v`.
+
+    An edit returns `lin + M^-1 w (g(f+d) - g(f))`: terms of size ~2 that cancel when the edit pushes a channel
+    towards zero.  float32 keeps that sum to ~3e-7 (a relative 3e-8 in `f` already moves it by 2e-7); the reference
+    computes it in float64.  The edit's own sRGB encode and the output encode then multiply the error by their
+    slopes: 12.92 each near black (167 together below 0.2225 of final value), ~3 at mid grey, ~1 at the top."""
+    if n_edits == 0:
+        return np.zeros_like(np.asarray(v, np.float64))
+    v = np.clip(np.asarray(v, np.float64), 0.0, 1.0)
+    inner = lv.eotf_sRGB(v) if output_encoded else v
+    slope = _encode_slope(lv.eotf_sRGB(inner))
+    if output_encoded:
+        slope = slope * _encode_slope(inner)
+    return n_edits * LAB_EDIT_ERR * slope
+
+
+@pytest.mark.parametrize("seed", fuzz_seeds(200))
+def test_random_stage_combinations(swatches, seed):
+    M_T, M_R = swatches
+    imgs, kw, recipe = fuzz_case(seed, M_T, M_R)
+    neg, ccm_kw, gains, sh, usm, final_clip, out = recipe
+    n_edits = (sh is not None) + (usm is not None)
     got = run_chain_dev(imgs, **kw)
-    for i in range(b):
-        pos = imgs[i]
-        want = _oracle_chain(pos, M_T, M_R, neg, ccm_kw, gains, sh, usm, final_clip, out)
+    for i in range(imgs.shape[0]):
+        want = _oracle_chain(imgs[i], M_T, M_R, *recipe)
         if out in ("u16", "u8"):
+            scale = 65535.0 if out == "u16" else 255.0
             diff = np.abs(got[i].astype(np.int64) - want.astype(np.int64))
-            # A Lab edit leaves a dark channel of a bright pixel as the small difference of terms of size ~0.5:
-            # float32 keeps ~1e-7 of it, and both sRGB encodes multiply that by 12.92 on their linear segments
-            # (the Lab stage's own encode below 0.0031 linear = 0.04 encoded, the output encode of that below
-            # 0.2225): there, and only there, a 16-bit result may be 2 steps off.
-            allowed = np.where((want < 0.23 * 65535) & (out == "u16") & (sh is not None or usm is not None), 2, 1)
+            # 1 step for an error below one step that crosses a truncation boundary; the Lab-edit term only reaches
+            # a whole step on 16-bit output of dark channels (167 * 3e-7 * 65535 = 3.3 steps per edit at worst)
+            extra = _lab_edit_allowance(want / scale, n_edits, True) * scale
+            allowed = 1 + np.floor(F32_TOL * scale + extra).astype(np.int64)
             assert np.all(diff <= allowed), (seed, list(kw.keys()), int(diff.max()))
         else:
             # polynomial corrections of high order lose absolute accuracy with the size of their terms
             tol = F32_TOL * (1 if ccm_kw is None or ccm_kw.get("terms", 3) <= 3 and ccm_kw.get("degree", 1) <= 1 else 4)
             err = np.abs(got[i] - want)
-            # (the dark-channel effect described above, on a float output that is encoded a second time)
-            edited_and_encoded = out == "f32_srgb" and (sh is not None or usm is not None)
-            allowed = np.where((want < 0.23) & edited_and_encoded, 3 * tol, tol)
+            allowed = tol + _lab_edit_allowance(want, n_edits, out == "f32_srgb")
             assert np.all(err <= allowed), (seed, out, ccm_kw, sh, usm, len(gains), float(err.max()))

@@ -5,7 +5,7 @@ tolerance 2e-6 absolute on [0,1] data: float32 accumulation against float64."""
 import numpy as np
 import pytest
 
-from gpu_util import DeviceBuffer
+from gpu_util import DeviceBuffer, fuzz_seeds
 from oracle import inputs
 from oracle import resize as orz
 from scanspaceimageprocessor_amd import default_context
@@ -89,7 +89,7 @@ def test_uint16_decoder_output_gives_the_same_previews():
     np.testing.assert_array_equal(il.thumbnail_from_array(small16), as_float[:100, :150])
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", fuzz_seeds(40))
 def test_random_shapes_and_scales(seed):
     # scales below 2, between 2 and 16 (the strip kernels: 64 / 128 / 256 destination pixels per workgroup) and above,
     # independent per axis, ragged sizes
