@@ -276,6 +276,36 @@ def test_usm_rows_carried_between_tiles(swatches, monkeypatch, max_wg, seg_tiles
         assert np.max(np.abs(got[i] - want)) <= F32_TOL
 
 
+@pytest.mark.parametrize("seed", fuzz_seeds(16))
+def test_sharpen_of_random_shapes_and_work_queues(swatches, monkeypatch, seed):
+    """Ragged tile grids of several hundred pixels a side, 1-3 images, random segment length and workgroup
+    limit (tile carries, ticket draws and steals in every mixture), against the float64 oracle."""
+    M_T, M_R = swatches
+    rng = np.random.default_rng(7000 + seed)
+    h, w, b = int(rng.integers(1, 420)), int(rng.integers(1, 760)), int(rng.integers(1, 4))
+    monkeypatch.setenv("SS_USM_MAX_WG", str(int(rng.choice([1, 2, 5, 13, 64, 4096]))))
+    monkeypatch.setenv("SS_USM_SEG_TILES", str(int(rng.choice([1, 2, 3, 5, 8, 64]))))
+    radius = float(rng.choice([0.5, 1.0, 1.5, 2.0, 2.5, 3.0]))
+    amount, threshold = float(rng.choice([1.0, 40.0, 80.0])), float(rng.choice([0.0, 2.0]))
+    with_ccm = bool(rng.random() < 0.5)
+    out = ["f32", "u16"][int(rng.integers(0, 2))]
+    imgs = np.stack([inputs.smooth_image(900 + 5 * seed + i, h, w) for i in range(b)])
+    kw = dict(gains=[1.1], usm=(amount, radius, threshold), final_clip=True, out=out)
+    if with_ccm:
+        kw["ccm"] = fit(M_T, M_R)
+    got = run_chain_dev(imgs, **kw)
+    for i in range(b):
+        x = lv.colour_correction(imgs[i], M_T, M_R) if with_ccm else imgs[i].astype(np.float64)
+        c = np.clip(oc.adjust_sharpen(np.clip(x * 1.1, 0, 1), amount, radius, threshold), 0, 1)
+        if out == "f32":
+            assert np.max(np.abs(got[i] - c)) <= F32_TOL, (seed, h, w, b, radius)
+        else:
+            want = np.clip(lv.eotf_inverse_sRGB(c) * 65535.0, 0, 65535.0).astype(np.uint16)
+            diff = np.abs(got[i].astype(np.int64) - want.astype(np.int64))
+            extra = _lab_edit_allowance(want / 65535.0, 1, True) * 65535.0
+            assert np.all(diff <= 1 + np.floor(F32_TOL * 65535.0 + extra)), (seed, h, w, b, radius, int(diff.max()))
+
+
 @pytest.mark.parametrize("radius,threshold", [(0.5, 0.0), (1.0, 3.0), (1.5, 0.0), (3.0, 1.0), (5.0, 0.0)])
 def test_usm_all_radii_f32(radius, threshold):
     img = inputs.smooth_image(61, 150, 210)
