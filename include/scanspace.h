@@ -225,6 +225,19 @@ int ss_exposure_multipliers(ss_ctx* ctx, const float* brightness_dev, int32_t n,
  * bit numpy's result.  n_values = height * width * 3 of a batch; both pointers 16-byte aligned.  Asynchronous. */
 int ss_unpack_u16(ss_ctx* ctx, const uint16_t* src_dev, float* dst_dev, uint64_t n_values);
 
+/* ---- Lab conversions as operators of their own ---------------------------------------------- */
+
+/* _rgb_to_lab (editingTools.py:367-386): colour.sRGB_to_XYZ (sRGB decode first) then colour.XYZ_to_Lab (D65).
+ * rgb_dev: n_pixels interleaved float32 triples; L_dev, a_dev, b_dev: n_pixels floats each (the three arrays the
+ * reference returns; L in 0..100).  Any input values: the piecewise functions pick their branch as numpy.where
+ * does in colour-science.  Asynchronous. */
+int ss_rgb_to_lab(ss_ctx* ctx, const float* rgb_dev, uint64_t n_pixels, float* L_dev, float* a_dev, float* b_dev);
+
+/* _lab_to_rgb (editingTools.py:389-408): colour.Lab_to_XYZ, colour.XYZ_to_sRGB (IEC 61966-2-1 matrix, sRGB
+ * encode), clip to [0, 1].  Planes in, n_pixels interleaved float32 triples out.  Asynchronous. */
+int ss_lab_to_rgb(ss_ctx* ctx, const float* L_dev, const float* a_dev, const float* b_dev, uint64_t n_pixels,
+                  float* rgb_dev);
+
 /* ---- LAB-input heuristic ------------------------------------------------------------------ */
 
 /* _is_lab_image (editingTools.py:411-432): max(ch0) > 1.5 and (min(ch1) < -1 or min(ch2) < -1).

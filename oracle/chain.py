@@ -170,6 +170,19 @@ def adjust_white_balance_gains(image, gains):
     return np.clip(adjusted, 0, 1)
 
 
+def sample_white_balance_from_point(image, sample_x, sample_y, current_temp, sample_radius=5):
+    """editingTools.py:643-711: window mean -> (R/G)/(B/G) -> logarithmic temperature shift, clamped to 1000..12000 K."""
+    h, w = image.shape[:2]
+    region = image[max(0, sample_y - sample_radius):min(h, sample_y + sample_radius + 1),
+                   max(0, sample_x - sample_radius):min(w, sample_x + sample_radius + 1)]
+    avg = np.mean(region, axis=(0, 1))
+    if avg[1] < 0.001:
+        return current_temp
+    rb = (avg[0] / avg[1]) / (avg[2] / avg[1] + 1e-10)
+    mult = 1 + np.log(rb) * 0.3 if rb > 1 else 1 / (1 + np.log(1 / rb) * 0.3)
+    return float(np.clip(current_temp * mult, 1000, 12000))
+
+
 def apply_all_adjustments(image, exposure=0.0, shadows=0.0, highlights=0.0, wb_gains=None,
                           sharpen_amount=0.0, sharpen_radius=1.0, sharpen_threshold=0.0):
     """editingTools.py:823-909 without the out-of-scope denoise stage.  White

@@ -121,6 +121,18 @@ def main():
     add("all_chart_mode_like", "linear", 53, 61, 83, ref.apply_all_adjustments,
         dict(exposure=0.25, shadows=35.0, highlights=0.4))
 
+    # a7 _rgb_to_lab / _lab_to_rgb (editingTools.py:367, 389)
+    add("rgb_to_lab_linear", "linear", 61, 48, 64, ref._rgb_to_lab, {})
+    add("rgb_to_lab_wide", "wide", 62, 33, 47, ref._rgb_to_lab, {})
+    add("lab_to_rgb", "lab", 63, 48, 64, lambda lab: ref._lab_to_rgb(lab[..., 0], lab[..., 1], lab[..., 2]), {})
+    # white balance picked from a point (editingTools.py:643)
+    add("wb_sample_centre", "linear", 64, 48, 64, ref.sample_white_balance_from_point,
+        dict(sample_x=30, sample_y=20, current_temp=5500.0))
+    add("wb_sample_corner", "negative", 65, 48, 64, ref.sample_white_balance_from_point,
+        dict(sample_x=0, sample_y=47, current_temp=4200.0, sample_radius=8))
+    add("wb_sample_wide", "wide", 66, 48, 64, ref.sample_white_balance_from_point,
+        dict(sample_x=63, sample_y=3, current_temp=9000.0, sample_radius=2))
+
     meta = {}
     arrays = {}
     for name, c in cases.items():

@@ -69,8 +69,53 @@ def ensure_positive_if_negative(image: np.ndarray, enabled: bool = False, low_pe
 
 
 # ---------------------------------------------------------------------------------------------
-# Lab helpers (reference editingTools.py:411-432)
+# Lab helpers (reference editingTools.py:367-432)
 # ---------------------------------------------------------------------------------------------
+
+
+def _rgb_to_lab(image: np.ndarray):
+    """``(L, a, b)`` planes of an sRGB-encoded image (reference editingTools.py:367-386): sRGB decode, XYZ, CIE Lab
+    under D65; L in 0..100.  float32 arrays of the image's leading shape."""
+    arr = np.ascontiguousarray(image, dtype=np.float32)
+    if arr.ndim < 1 or arr.shape[-1] != 3:
+        raise ValueError(f"expected (..., 3) RGB data, got shape {arr.shape}")
+    n = arr.size // 3
+    planes = np.empty((3, n), dtype=np.float32)
+    if n == 0:
+        return tuple(planes[k].reshape(arr.shape[:-1]) for k in range(3))
+    ctx = default_context()
+    src = ctx.malloc(arr.nbytes)
+    dst = ctx.malloc(planes.nbytes)
+    try:
+        ctx.upload(src, arr)
+        ctx.rgb_to_lab(src, n, dst, dst + 4 * n, dst + 8 * n)
+        ctx.download(planes, dst)
+    finally:
+        ctx.free(src)
+        ctx.free(dst)
+    return tuple(planes[k].reshape(arr.shape[:-1]) for k in range(3))
+
+
+def _lab_to_rgb(L: np.ndarray, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """sRGB-encoded image, clipped to [0, 1], of three Lab planes (reference editingTools.py:389-408)."""
+    L = np.asarray(L)
+    planes = np.ascontiguousarray(np.stack([np.broadcast_to(np.asarray(p, dtype=np.float32), L.shape)
+                                            for p in (L, a, b)]).reshape(3, -1))
+    n = planes.shape[1]
+    out = np.empty(L.shape + (3,), dtype=np.float32)
+    if n == 0:
+        return out
+    ctx = default_context()
+    src = ctx.malloc(planes.nbytes)
+    dst = ctx.malloc(out.nbytes)
+    try:
+        ctx.upload(src, planes)
+        ctx.lab_to_rgb(src, src + 4 * n, src + 8 * n, n, dst)
+        ctx.download(out, dst)
+    finally:
+        ctx.free(src)
+        ctx.free(dst)
+    return out
 
 
 def _is_lab_image(image: np.ndarray) -> bool:
@@ -168,6 +213,56 @@ def adjust_white_balance(image: np.ndarray, current_temp: float, target_temp: fl
         return image
     out, _ = _run(image, gains=[calculate_white_balance_multipliers(current_temp, target_temp, tint)])
     return out
+
+
+def sample_white_balance_from_point(image: np.ndarray, sample_x: int, sample_y: int, current_temp: float,
+                                    sample_radius: int = 5) -> float:
+    """Colour temperature that neutralises the patch around a picked point (reference editingTools.py:643-711).
+
+    Mean colour of the ``(2 r + 1)^2`` window clipped to the image; with ``q = (R/G) / (B/G)`` the new temperature
+    is ``T (1 + 0.3 ln q)`` for a reddish patch (q > 1) and ``T / (1 + 0.3 ln(1/q))`` otherwise, limited to
+    1000..12000 K.  A patch whose mean green is below 0.001 leaves ``current_temp`` as it is.  Host arithmetic:
+    the window holds 121 pixels."""
+    height, width = image.shape[:2]
+    rows = slice(max(0, sample_y - sample_radius), min(height, sample_y + sample_radius + 1))
+    cols = slice(max(0, sample_x - sample_radius), min(width, sample_x + sample_radius + 1))
+    red, green, blue = np.mean(image[rows, cols], axis=(0, 1))[:3]
+    if green < 0.001:
+        return current_temp
+    q = (red / green) / (blue / green + 1e-10)
+    factor = 1.0 + 0.3 * np.log(q) if q > 1 else 1.0 / (1.0 + 0.3 * np.log(1.0 / q))
+    return float(np.clip(current_temp * factor, 1000, 12000))
+
+
+# ---------------------------------------------------------------------------------------------
+# cache hooks of the reference's preview path (editingTools.py:206-254)
+# ---------------------------------------------------------------------------------------------
+# The reference keeps denoised previews in a memory-managed cache and lets the GUI steer it.  Denoise is not
+# part of this package, nothing is cached, and a fused pass over a 4 MP preview takes well under a millisecond
+# of GPU time; the hooks stay so that callers of the reference's module find them.
+
+_CURRENT_IMAGE_ID = None
+
+
+def clear_adjustment_cache() -> None:
+    global _CURRENT_IMAGE_ID
+    _CURRENT_IMAGE_ID = None
+
+
+def set_current_image_id(image_id: str) -> None:
+    global _CURRENT_IMAGE_ID
+    _CURRENT_IMAGE_ID = image_id
+
+
+def get_cache_stats() -> dict:
+    """The reference's statistics record (editingTools.py:173-184) of an always-empty cache."""
+    return {'entries': 0, 'memory_mb': 0.0, 'memory_percent': 0.0, 'hits': 0, 'misses': 0, 'evictions': 0,
+            'hit_rate': 0}
+
+
+def check_memory_usage() -> bool:
+    """True when a cleanup was performed (reference editingTools.py:224-254): there is never anything to clean."""
+    return False
 
 
 # ---------------------------------------------------------------------------------------------

@@ -104,6 +104,8 @@ SIGNATURES = {
                                           C.c_int32, C.c_void_p]),
     "ss_unpack_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ss_is_lab_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ss_rgb_to_lab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ss_lab_to_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ss_mask_regions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                   C.c_int32, C.c_void_p]),
     "ss_resize_area": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -290,6 +292,16 @@ class Context:
     def is_lab_image(self, src_dev, n_pixels, out_dev, minmax_dev=None):
         self.check(self.lib.ss_is_lab_image(self.handle, C.c_void_p(src_dev), int(n_pixels),
                                             C.c_void_p(out_dev), C.c_void_p(minmax_dev or None)))
+
+    def rgb_to_lab(self, rgb_dev, n_pixels, L_dev, a_dev, b_dev):
+        """Interleaved sRGB-encoded float32 pixels -> planes L, a, b (asynchronous)."""
+        self.check(self.lib.ss_rgb_to_lab(self.handle, C.c_void_p(rgb_dev), int(n_pixels), C.c_void_p(L_dev),
+                                          C.c_void_p(a_dev), C.c_void_p(b_dev)))
+
+    def lab_to_rgb(self, L_dev, a_dev, b_dev, n_pixels, rgb_dev):
+        """Planes L, a, b -> interleaved sRGB-encoded float32 pixels clipped to [0, 1] (asynchronous)."""
+        self.check(self.lib.ss_lab_to_rgb(self.handle, C.c_void_p(L_dev), C.c_void_p(a_dev), C.c_void_p(b_dev),
+                                          int(n_pixels), C.c_void_p(rgb_dev)))
 
     def mask_regions(self, img_dev, height, width, batch, shadow_limit, highlight_limit, min_area=200, count_dev=None):
         """Zero, in place, the 8-connected regions of at least ``min_area`` pixels whose luminance is <= shadow_limit

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libscanspace_hip.so")
-SOURCES = ["chain.hip", "usm.hip", "stats.hip", "resize.hip", "mask.hip", "api.hip"]
+SOURCES = ["chain.hip", "usm.hip", "stats.hip", "resize.hip", "mask.hip", "lab.hip", "api.hip"]
 HEADERS = ["ss_device.h", "ss_internal.h", os.path.join("..", "..", "include", "scanspace.h")]
 # The pixel pipelines pack their pair arithmetic explicitly (v_pk_*_f32).  The SLP vectoriser's own pairs need
 # aligned register pairs, and the copies it inserts for them wait on the pixel loads: without it the tile kernel's

@@ -568,6 +568,27 @@ int ss_is_lab_image(ss_ctx* c, const float* src_dev, int64_t n_pixels, int32_t* 
   return SS_OK;
 }
 
+int ss_rgb_to_lab(ss_ctx* c, const float* rgb_dev, uint64_t n_pixels, float* L_dev, float* a_dev, float* b_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!rgb_dev || !L_dev || !a_dev || !b_dev) return fail(c, SS_ERR_INVALID, "NULL pointer");
+  if (n_pixels == 0) return SS_OK;
+  hipError_t e = launch_rgb_to_lab(rgb_dev, n_pixels, L_dev, a_dev, b_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "rgb->lab kernel failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_lab_to_rgb(ss_ctx* c, const float* L_dev, const float* a_dev, const float* b_dev, uint64_t n_pixels,
+                  float* rgb_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!rgb_dev || !L_dev || !a_dev || !b_dev) return fail(c, SS_ERR_INVALID, "NULL pointer");
+  if (n_pixels == 0) return SS_OK;
+  hipError_t e = launch_lab_to_rgb(L_dev, a_dev, b_dev, n_pixels, rgb_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "lab->rgb kernel failed to launch: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
 int ss_unpack_u16(ss_ctx* c, const uint16_t* src_dev, float* dst_dev, uint64_t n_values) {
   int rc = check_ctx(c);
   if (rc) return rc;

@@ -55,6 +55,10 @@ hipError_t launch_unpack_u16(const uint16_t* src, float* dst, uint64_t n, hipStr
 // area-average downscale (resize.hip); dh <= sh, dw <= sw
 hipError_t launch_resize_area(const float* src, int sh, int sw, int batch, float* dst, int dh, int dw, hipStream_t st);
 
+// _rgb_to_lab / _lab_to_rgb as operators of their own (lab.hip): interleaved RGB <-> planes L, a, b
+hipError_t launch_rgb_to_lab(const float* rgb, uint64_t n_px, float* L, float* a, float* b, hipStream_t st);
+hipError_t launch_lab_to_rgb(const float* L, const float* a, const float* b, uint64_t n_px, float* rgb, hipStream_t st);
+
 hipError_t launch_is_lab(const float* src, int64_t n_px, float* partials /*[kLabDetectBlocks][3]*/, int32_t* out,
                          float* minmax, hipStream_t st);
 

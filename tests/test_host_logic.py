@@ -208,3 +208,31 @@ def test_neutral_settings_need_no_gpu():
     assert out is not img and np.array_equal(out, img)
     g = et.GlobalAdjustments()
     assert g.apply_to_image(img) is img and not g.has_adjustments()
+
+
+def test_white_balance_picked_from_a_point_against_reference_vectors(golden):
+    """sample_white_balance_from_point (reference editingTools.py:643-711): host arithmetic on the picked window."""
+    from conftest import golden_input
+    from scanspaceimageprocessor_amd.ImageProcessor import editingTools as et
+
+    meta, data = golden
+    for name in ("wb_sample_centre", "wb_sample_corner", "wb_sample_wide"):
+        img = golden_input(meta[name])
+        got = et.sample_white_balance_from_point(img, **meta[name]["kwargs"])
+        assert isinstance(got, float)
+        np.testing.assert_allclose(got, float(data[name]), rtol=1e-7)
+    dark = np.full((9, 9, 3), 0.0005, np.float32)
+    assert et.sample_white_balance_from_point(dark, 4, 4, 5100.0) == 5100.0   # too dark to judge: unchanged
+    red = np.zeros((9, 9, 3), np.float32) + np.array([0.9, 0.3, 0.001], np.float32)
+    assert et.sample_white_balance_from_point(red, 4, 4, 9000.0) == 12000.0   # clamped
+
+
+def test_cache_hooks_of_the_preview_path_exist_and_hold_nothing():
+    from scanspaceimageprocessor_amd.ImageProcessor import editingTools as et
+
+    et.set_current_image_id("a.nef")
+    et.clear_adjustment_cache()
+    stats = et.get_cache_stats()
+    assert stats["entries"] == 0 and set(stats) == {"entries", "memory_mb", "memory_percent", "hits", "misses",
+                                                    "evictions", "hit_rate"}
+    assert et.check_memory_usage() is False

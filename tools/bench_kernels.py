@@ -65,7 +65,7 @@ def main():
 
     todo = args.configs.split(",")
     H, W, B = 4000, 6000, args.batch
-    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "1c", "5", "5p", "5b", "5c", "t", "m")):
+    if any(c in todo for c in ("1", "2", "2b", "2r1", "3", "1u16", "1u8", "1c", "5", "5p", "5b", "5c", "t", "m", "l")):
         img = images(H, W, B)
         out = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
     if "1" in todo:
@@ -105,6 +105,14 @@ def main():
             ccm = matrix_colour_correction(M_T, M_R, **kw)
             d = make_desc(H, W, B, ccm=ccm, gains=[1.0], out="f32_srgb")
             report(f"1c {name}+clip+srgb f32", H, W, B, 24, *timeit(lambda: ctx.chain_run(d, img.data_ptr(), out.data_ptr())))
+    if "l" in todo:  # the Lab helpers as operators of their own: interleaved RGB <-> planes L, a, b
+        n = B * H * W
+        report("l  _rgb_to_lab", H, W, B, 24, *timeit(lambda: ctx.rgb_to_lab(
+            img.data_ptr(), n, out.data_ptr(), out.data_ptr() + 4 * n, out.data_ptr() + 8 * n)))
+        back = torch.empty_like(img)
+        report("l  _lab_to_rgb", H, W, B, 24, *timeit(lambda: ctx.lab_to_rgb(
+            out.data_ptr(), out.data_ptr() + 4 * n, out.data_ptr() + 8 * n, n, back.data_ptr())))
+        del back
     if "t" in todo:  # preview / thumbnail producers: 24 MP -> 512 x 341 and -> 1 MP
         for name, (dw, dh) in (("512px thumbnail", (512, 341)), ("1 MP preview", (1224, 816))):
             small = torch.empty((B, dh, dw, 3), dtype=torch.float32, device=dev)
