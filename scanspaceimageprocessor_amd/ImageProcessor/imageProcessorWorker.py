@@ -358,6 +358,22 @@ class ImageCorrectionWorker:
 
         write_image(out_path, encoded, ext, self.jpeg_quality, exr_colorspace=self.exr_colorspace)
 
+    # the reference's per-format writers (imageProcessorWorker.py:604-662), same names; `encode_image` made the array
+    def export_image_jpg(self, img_array: np.ndarray, output_path: str):
+        self._write(output_path, img_array, '.jpg')
+
+    def export_image_png(self, img_array: np.ndarray, output_path: str):
+        self._write(output_path, img_array, '.png')
+
+    def export_image_tiff(self, img_array: np.ndarray, output_path: str):
+        self._write(output_path, img_array, '.tiff')
+
+    def export_image_exr(self, img_array: np.ndarray, output_path: str):
+        """Writes the float image as scene-linear EXR in ``exr_colorspace`` and returns ``(None, preview_uint8)``:
+        the reference returns its OpenImageIO buffer first, which only its metadata step reads."""
+        self._write(output_path, img_array, '.exr')
+        return None, np.uint8(np.clip(img_array * 255.0, 0, 255))
+
     def construct_export_path(self, img_path: str) -> str:
         """Reference imageProcessorWorker.py:664-746: the server's path in network mode, else the naming schema
         (when the host application supplies ``fileNamingSchema.apply_naming_schema``; any failure falls back to

@@ -92,3 +92,23 @@ def test_exr_round_trip_and_layout(tmp_path):
         import OpenImageIO as oiio
 
         np.testing.assert_array_equal(np.asarray(oiio.ImageBuf(path).get_pixels(oiio.FLOAT)), arr)
+
+
+def test_worker_export_methods_write_the_named_formats(tmp_path):
+    """export_image_tiff / png / exr of the worker (reference imageProcessorWorker.py:604-662) by their names."""
+    from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as ipw
+
+    w = ipw.ImageCorrectionWorker(["a.nef"], None, str(tmp_path), None, output_format=".tiff", tiff_bitdepth=16)
+    rng = np.random.default_rng(6)
+    u16 = rng.integers(0, 65536, size=(9, 13, 3), dtype=np.uint16)
+    w.export_image_tiff(u16, str(tmp_path / "a.tiff"))
+    np.testing.assert_array_equal(iw.read_tiff(str(tmp_path / "a.tiff")), u16)
+    u8 = rng.integers(0, 256, size=(9, 13, 3), dtype=np.uint8)
+    w.export_image_png(u8, str(tmp_path / "a.png"))
+    assert (tmp_path / "a.png").stat().st_size > 0
+    lin = rng.random((9, 13, 3)).astype(np.float32)
+    buf, preview = w.export_image_exr(lin, str(tmp_path / "a.exr"))
+    assert buf is None and preview.dtype == np.uint8 and preview.shape == lin.shape
+    np.testing.assert_array_equal(preview, np.uint8(np.clip(lin * 255.0, 0, 255)))
+    back, attrs = iw.read_exr(str(tmp_path / "a.exr"))
+    np.testing.assert_array_equal(back, lin)
