@@ -119,3 +119,118 @@ def resize_for_preview(img_array, max_preview_pixels=EDIT_PREVIEW_PIXELS, ctx=No
     if size is None:
         return img_array
     return resize_area(img_array, size, ctx)
+
+
+RAW_EXTENSIONS = ('.nef', '.cr2', '.cr3', '.dng', '.arw', '.raw')
+
+
+class ImageLoader:
+    """The array-producing half of the reference's ``ImageLoader`` (imageLoader.py:130-306).  File decoding stays
+    on the host (Pillow for rendered formats, rawpy for RAW, both looked up when called); negative inversion, colour
+    correction, encoding and the area downscale run on the GPU.  Pixmap conversion is Qt's business."""
+
+    @staticmethod
+    def load_thumbnail_array(path, max_size=(512, 512), cache=None, chart_swatches=None, correct_thumbnails=False,
+                             log_callback=None, negative_mode: bool = False):
+        """Thumbnail of an image file as an RGB array, or None (reference imageLoader.py:185-261).
+
+        float32 in 0..1; with ``chart_swatches`` and ``correct_thumbnails`` the colour-corrected, sRGB-encoded
+        uint8 array the reference returns in that case.  Kept from the reference: a cache hit short-circuits
+        everything; results are stored only in a cache that already holds something (``if cache:``); a failing
+        correction is logged and the uncorrected array returned; RAW files Pillow cannot open take
+        ``_load_raw_thumbnail``; anything else is logged and yields None."""
+        import os
+
+        from .editingTools import ensure_positive_if_negative
+
+        if cache:
+            cached = cache.get(path)
+            if cached and 'array' in cached and cached['array'] is not None:
+                return cached['array']
+
+        def log(msg):
+            if log_callback:
+                log_callback(msg)
+
+        def remember(arr):
+            if cache:
+                cache[path] = cache.get(path, {})
+                cache[path]['array'] = arr
+            return arr
+
+        try:
+            from PIL import Image
+
+            with Image.open(path) as img:
+                img.thumbnail(max_size)
+                arr = np.asarray(img, dtype=np.float32) / 255.0
+        except Exception as e:
+            if os.path.splitext(path)[1].lower() in RAW_EXTENSIONS:
+                try:
+                    arr = ImageLoader._load_raw_thumbnail(path, max_size, log_callback)
+                    if arr is not None and negative_mode:
+                        arr = ensure_positive_if_negative(arr, enabled=True)
+                    if arr is not None:
+                        remember(arr)
+                    return arr
+                except Exception as e2:
+                    log(f"[Thumb] RAW fallback failed: {e2}")
+            log(f"[Thumb] Could not load thumbnail: {e}")
+            return None
+        if negative_mode:
+            arr = ensure_positive_if_negative(arr, enabled=True)
+        if chart_swatches is not None and correct_thumbnails:
+            try:
+                arr = ImageLoader.correct_thumbnail(arr, chart_swatches)
+                log("[Thumb] Applied colour correction to thumbnail.")
+            except Exception as e:
+                log(f"[Thumb] Colour correction on thumbnail failed: {e}")
+        return remember(arr)
+
+    @staticmethod
+    def correct_thumbnail(arr, chart_swatches, reference=None):
+        """``np.uint8(255 * cctf_encoding(clip(colour_correction(arr, chart_swatches, reference), 0, 1)))``
+        (imageLoader.py:226-228) as one fused pass: 3-term Cheung fit on the host, matrix, clip, sRGB encode and
+        truncation to 8 bits on the device."""
+        from ..chain import make_desc
+        from ..colour_fit import matrix_colour_correction
+        from . import imageProcessorWorker as ipw
+
+        reference = ipw.reference_swatches if reference is None else reference
+        if reference is None:
+            raise RuntimeError("no reference swatch table: call set_reference_swatches first")
+        arr = _check_image(arr)
+        ccm = matrix_colour_correction(np.asarray(chart_swatches), np.asarray(reference))
+        h, w, _ = arr.shape
+        desc = make_desc(h, w, 1, ccm=ccm, final_clip=True, out="u8")
+        out, _ = default_context().chain_run_host(desc, np.ascontiguousarray(arr, dtype=np.float32))
+        return out
+
+    @staticmethod
+    def _load_raw_thumbnail(path, max_size, log_callback=None):
+        """Reference imageLoader.py:264-306: the embedded JPEG when the RAW file has one, else an 8-bit decode shrunk
+        (area average, on the GPU) to fit ``max_size``."""
+        import io
+
+        import rawpy  # host decode stays on LibRaw
+        from PIL import Image
+
+        def log(msg):
+            if log_callback:
+                log_callback(msg)
+
+        with rawpy.imread(path) as raw:
+            try:
+                thumb = raw.extract_thumb()
+                if thumb.format == rawpy.ThumbFormat.JPEG:
+                    pil = Image.open(io.BytesIO(thumb.data))
+                    pil.thumbnail(max_size)
+                    log("[Thumb] Loaded embedded JPEG thumbnail from RAW.")
+                    return np.asarray(pil, dtype=np.float32) / 255.0
+                log("[Thumb] No embedded JPEG, using raw postprocess.")
+            except Exception:
+                log("[Thumb] No embedded thumbnail, using raw postprocess.")
+            rgb = raw.postprocess(output_bps=8, no_auto_bright=True)
+        arr = thumbnail_from_array(rgb.astype(np.float32) / 255.0, max_size)
+        log("[Thumb] Loaded thumbnail from rawpy postprocess.")
+        return arr
