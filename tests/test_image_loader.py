@@ -103,3 +103,27 @@ def test_negative_mode_inverts_the_thumbnail(tmp_path):
     want = oc.invert_negative_auto(thumb, legacy=True)
     assert got.dtype == np.float32
     assert np.max(np.abs(got - want)) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_swatch_preview_worker_and_overlay_encoding():
+    """image_space.py:98-129 and 4098-4113: corrected 8-bit previews and plain 8-bit encodes."""
+    from scanspaceimageprocessor_amd.ImageProcessor import previewWorkers as pw
+
+    M_T, M_R = inputs.synthetic_swatches()
+    img = inputs.linear_image(12, 211, 307)
+    got, errors = [], []
+    w = pw.SwatchPreviewWorker(img, M_T, M_R)
+    w.signals.finished.connect(got.append)
+    w.signals.error.connect(errors.append)
+    w.run()
+    assert not errors and len(got) == 1
+    want = np.uint8(255 * lv.eotf_inverse_sRGB(np.clip(lv.colour_correction(img, M_T, M_R), 0, 1)))
+    assert got[0].dtype == np.uint8 and np.max(np.abs(got[0].astype(np.int32) - want.astype(np.int32))) <= 1
+    plain = pw.encode_preview_u8(img)
+    want_plain = np.uint8(255 * lv.eotf_inverse_sRGB(img.astype(np.float64)))
+    assert np.max(np.abs(plain.astype(np.int32) - want_plain.astype(np.int32))) <= 1
+    bad = pw.SwatchPreviewWorker(img[..., 0], M_T, M_R)   # not an RGB image: reported, not raised
+    bad.signals.error.connect(errors.append)
+    bad.run()
+    assert len(errors) == 1 and "expected an (H, W, 3) image" in errors[0]
