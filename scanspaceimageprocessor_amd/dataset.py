@@ -89,3 +89,66 @@ class ExposureNormaliser:
         self.ctx.exposure_multipliers(self.brightness_all.data_ptr(), self.n_images, self.chart_index,
                                       self.first, self.count, self.gains.data_ptr())
         return self.gains
+
+
+def calculate_average_exposure(thumbnails, shadow_limit: float = 0.06, highlight_limit: float = 0.96,
+                               average_source=None, ctx=None, log=None) -> dict:
+    """Exposure multipliers of a dataset from its thumbnails: the arithmetic of the main window's
+    ``calculate_average_exposure`` (image_space.py:4323-4398) without the widget plumbing.
+
+    ``thumbnails`` maps image path -> ``(H, W, 3)`` array (the thumbnail cache's ``'array'`` entries) in list
+    order; a ``None`` entry is reported and skipped, as the reference does for a thumbnail it could not load.
+    ``shadow_limit`` / ``highlight_limit`` are the spin-box values divided by 100.  ``average_source``: path of
+    the chart image whose brightness is the reference, or None for the mean over all images.
+    Returns path -> multiplier (what the reference stores as ``meta['average_exposure']`` and the worker reads
+    through ``image_metadata_map``); empty when no thumbnail was usable.
+
+    Masked luminance means run on the GPU, one launch per thumbnail shape (a dataset has one or two), and the
+    multipliers in one more launch."""
+    import numpy as np
+
+    from ._lib import default_context
+
+    say = log or (lambda msg: None)
+    ctx = ctx or default_context()
+    paths, arrays = [], []
+    for path, arr in thumbnails.items():
+        if arr is None:
+            say(f"[Exposure Calc] Failed on {path}: could not load thumbnail")
+            continue
+        arr = np.asarray(arr, dtype=np.float32)
+        if arr.ndim != 3 or arr.shape[2] < 3:
+            say(f"[Exposure Calc] Failed on {path}: not an RGB thumbnail")
+            continue
+        paths.append(path)
+        arrays.append(np.ascontiguousarray(arr[:, :, :3]))
+    if not paths:
+        say("[Exposure Calc] No valid images for exposure normalization.")
+        return {}
+    n = len(paths)
+    by_shape = {}
+    for i, arr in enumerate(arrays):
+        by_shape.setdefault(arr.shape, []).append(i)
+    brightness = np.empty(n, dtype=np.float32)
+    for (h, w, _), members in by_shape.items():
+        batch = np.stack([arrays[i] for i in members])
+        src = ctx.workspace("exposure.thumbs", batch.nbytes)
+        out = ctx.workspace("exposure.brightness", 4 * len(members))
+        ctx.upload(src, batch)
+        ctx.exposure_stats(src, h, w, len(members), shadow_limit, highlight_limit, None, out)
+        values = np.empty(len(members), dtype=np.float32)
+        ctx.download(values, out)
+        brightness[members] = values
+    ref_index = paths.index(average_source) if average_source in paths else None
+    all_dev = ctx.workspace("exposure.all", 4 * n)
+    mult_dev = ctx.workspace("exposure.mult", 4 * n)
+    ctx.upload(all_dev, brightness)
+    ctx.exposure_multipliers(all_dev, n, ref_index, 0, n, mult_dev)
+    mult = np.empty(n, dtype=np.float32)
+    ctx.download(mult, mult_dev)
+    if ref_index is None:
+        say(f"[Exposure Calc] Using average image brightness as reference ({float(np.mean(brightness)):.3f})")
+    for path, m in zip(paths, mult):
+        say(f"[Exposure Calc] {path} multiplier: {float(m):.3f}")
+    say("[Exposure Calc] Average exposure multipliers calculated and stored.")
+    return {path: float(m) for path, m in zip(paths, mult)}

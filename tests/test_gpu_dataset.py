@@ -55,3 +55,33 @@ def test_exposure_normaliser_with_an_rccl_all_gather_on_the_context_stream():
         np.testing.assert_allclose(norm.brightness_all.cpu().numpy(), want_b, rtol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_calculate_average_exposure_over_mixed_thumbnail_shapes():
+    """The main window's calculate_average_exposure (image_space.py:4323-4398) on a dict of thumbnails: landscape
+    and portrait shapes, one thumbnail missing, reference = mean of all or the chart image."""
+    from scanspaceimageprocessor_amd.dataset import calculate_average_exposure
+
+    rng = np.random.default_rng(11)
+    thumbs = {}
+    for i in range(7):
+        h, w = (341, 512) if i % 3 else (512, 341)
+        thumbs[f"/d/img_{i}.nef"] = inputs.linear_image(40 + i, h, w) * np.float32(2.0 ** rng.uniform(-0.6, 0.6))
+    thumbs["/d/img_missing.nef"] = None
+    thumbs["/d/img_black.nef"] = np.zeros((341, 512, 3), np.float32)
+    logs = []
+    got = calculate_average_exposure(thumbs, 0.06, 0.96, log=logs.append)
+    usable = [p for p, a in thumbs.items() if a is not None]
+    assert list(got) == usable
+    want_b = [oc.image_brightness(thumbs[p], 0.06, 0.96) for p in usable]
+    want = oc.exposure_multipliers(want_b, None)
+    np.testing.assert_allclose([got[p] for p in usable], want, rtol=1e-6)
+    assert got["/d/img_black.nef"] == 1.0                                  # brightness 0: multiplier 1
+    assert logs[0] == "[Exposure Calc] Failed on /d/img_missing.nef: could not load thumbnail"
+    assert any(m.startswith("[Exposure Calc] Using average image brightness as reference") for m in logs)
+    chart = "/d/img_3.nef"
+    got_c = calculate_average_exposure(thumbs, 0.06, 0.96, average_source=chart)
+    want_c = oc.exposure_multipliers(want_b, usable.index(chart))
+    np.testing.assert_allclose([got_c[p] for p in usable], want_c, rtol=1e-6)
+    assert got_c[chart] == 1.0
+    assert calculate_average_exposure({"/d/x.nef": None}, log=logs.append) == {}
