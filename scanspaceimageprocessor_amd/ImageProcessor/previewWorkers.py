@@ -61,3 +61,36 @@ class SwatchPreviewWorker:
             self.signals.finished.emit(corrected_preview_u8(self.img_fp, self.swatch_colours, self.reference_swatches))
         except Exception as e:
             self.signals.error.emit(str(e))
+
+
+FAST_DISPLAY_MAX_PIXELS = 500_000  # image_space.py:3052: previews this small are shown without the sRGB encode
+
+
+def display_u8(img_array) -> np.ndarray:
+    """The array half of ``MainWindow._array_to_pixmap`` (image_space.py:3039-3058): ``uint8(255 * clip(x, 0, 1))``
+    for images of at most 0.5 MP, ``uint8(255 * cctf_encoding(clip(x, 0, 1)))`` above."""
+    img = np.ascontiguousarray(img_array, dtype=np.float32)
+    h, w = img.shape[:2]
+    out_kind = "u8_linear" if h * w <= FAST_DISPLAY_MAX_PIXELS else "u8"
+    out, _ = default_context().chain_run_host(make_desc(h, w, 1, final_clip=True, out=out_kind), img)
+    return out
+
+
+def adjusted_preview_u8(preview_array, **adjustments) -> np.ndarray:
+    """``_update_preview_display`` (image_space.py:2988-3037) up to the pixmap: ``apply_all_adjustments`` with the
+    given keyword arguments followed by ``_array_to_pixmap``'s conversion, as ONE fused pass from the float preview
+    to display bytes (the float result never leaves the GPU)."""
+    from .editingTools import adjustment_stages, apply_all_adjustments
+
+    img = np.ascontiguousarray(preview_array, dtype=np.float32)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError(f"Invalid preview array shape: {img.shape}")
+    kw = adjustment_stages(**adjustments)
+    if not kw["gains"] and ("sh" in kw or "usm" in kw):
+        # the Lab stages come first: they look at the data to tell LAB input from RGB, and LAB output is not a
+        # display format, so this rare combination takes the two passes the reference takes
+        return display_u8(apply_all_adjustments(img, **adjustments))
+    h, w = img.shape[:2]
+    out_kind = "u8_linear" if h * w <= FAST_DISPLAY_MAX_PIXELS else "u8"
+    out, _ = default_context().chain_run_host(make_desc(h, w, 1, final_clip=True, out=out_kind, **kw), img)
+    return out

@@ -127,3 +127,27 @@ def test_swatch_preview_worker_and_overlay_encoding():
     bad.signals.error.connect(errors.append)
     bad.run()
     assert len(errors) == 1 and "expected an (H, W, 3) image" in errors[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(400, 600), (800, 1000)])   # below and above the 0.5 MP display rule
+def test_adjusted_preview_bytes_match_adjust_then_convert(shape):
+    """image_space.py:2988-3058: apply_all_adjustments, then uint8(255 * clip) or uint8(255 * encode(clip))."""
+    from scanspaceimageprocessor_amd.ImageProcessor import previewWorkers as pw
+
+    img = inputs.smooth_image(31, *shape)
+    small = shape[0] * shape[1] <= 500_000
+
+    def to_bytes(x):
+        x = np.clip(x, 0, 1)
+        return np.uint8(255 * (x if small else lv.eotf_inverse_sRGB(x)))
+
+    for adj, wb in ((dict(exposure=0.4, shadows=20.0, highlights=-0.5, sharpen_amount=35.0), None),
+                    (dict(shadows=30.0, sharpen_amount=50.0), None),         # Lab stages first: the two-pass route
+                    (dict(), None)):
+        got = pw.adjusted_preview_u8(img, **adj)
+        want = to_bytes(oc.apply_all_adjustments(img, **adj))
+        assert got.dtype == np.uint8 and got.shape == img.shape
+        diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 1, (adj, int(diff.max()))
+    np.testing.assert_array_equal(pw.display_u8(img), pw.adjusted_preview_u8(img))
