@@ -122,8 +122,9 @@ struct __attribute__((aligned(4))) F4 {  // 16 bytes at 4-byte alignment: one gl
 };
 
 // kTileDx destination pixels per workgroup: 64 / 128 / 256 for scales up to 16 / 8 / 4, so that the strip (and with
-// it every thread's accumulators) is well filled at any scale.
-template <int kTileDx>
+// it every thread's accumulators) is well filled at any scale.  kRowBatch: source rows whose loads are issued together
+// (a strong reduction covers many rows and gains from more loads in flight; a weak one covers few).
+template <int kTileDx, int kRowBatch>
 __global__ __launch_bounds__(kTileThreads) void resize_area_tiled_kernel(const float* __restrict__ src,
                                                                          float* __restrict__ dst, int sh, int sw, int dh,
                                                                          int dw, double scale_y, double scale_x) {
@@ -143,24 +144,41 @@ __global__ __launch_bounds__(kTileThreads) void resize_area_tiled_kernel(const f
   for (int k = 0; k < kTileVecs; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0f;
   const int has_head = ay.a_head != 0.0f ? 1 : 0, has_tail = ay.a_tail != 0.0f ? 1 : 0;
   const int n_rows = has_head + (ay.last - ay.first) + has_tail;
-  for (int i = 0; i < n_rows; ++i) {
-    const int sy = ay.first - has_head + i;
-    const float beta = (i < has_head) ? ay.a_head : (sy < ay.last ? ay.a_full : ay.a_tail);
-    const float* __restrict__ row = s + ((size_t)sy * sw + sx_begin) * 3;
+  // kRowBatch source rows per trip: all their loads are issued before the first is folded, so a thread keeps up to
+  // kRowBatch * kTileVecs 16-byte loads in flight.  Rows past the end are not loaded and fold zeros with weight 0; the
+  // folding order (row after row) is unchanged.
+  for (int i0 = 0; i0 < n_rows; i0 += kRowBatch) {
+    F4 v[kRowBatch][kTileVecs];
+    float beta[kRowBatch];
 #pragma unroll
-    for (int k = 0; k < kTileVecs; ++k) {
-      const int f = (tid + k * kTileThreads) * 4;
-      if (f + 4 <= n_floats) {
-        // (cached loads: the strips' 16-byte accesses are not line-aligned, neighbouring ones complete a line)
-        const F4 v = *reinterpret_cast<const F4*>(row + f);
-        acc[k][0] = fmaf(v.x, beta, acc[k][0]);
-        acc[k][1] = fmaf(v.y, beta, acc[k][1]);
-        acc[k][2] = fmaf(v.z, beta, acc[k][2]);
-        acc[k][3] = fmaf(v.w, beta, acc[k][3]);
-      } else {
+    for (int r = 0; r < kRowBatch; ++r) {
+      const bool on = i0 + r < n_rows;
+      const int i = on ? i0 + r : n_rows - 1;
+      const int sy = ay.first - has_head + i;
+      beta[r] = !on ? 0.0f : (i < has_head) ? ay.a_head : (sy < ay.last ? ay.a_full : ay.a_tail);
+      const float* __restrict__ row = s + ((size_t)sy * sw + sx_begin) * 3;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (f + j < n_floats) acc[k][j] = fmaf(row[f + j], beta, acc[k][j]);
+      for (int k = 0; k < kTileVecs; ++k) {
+        const int f = (tid + k * kTileThreads) * 4;
+        if (!on) {  // (uniform over the workgroup)
+          v[r][k] = F4{0.0f, 0.0f, 0.0f, 0.0f};
+        } else if (f + 4 <= n_floats) {
+          // (cached loads: the strips' 16-byte accesses are not line-aligned, neighbouring ones complete a line)
+          v[r][k] = *reinterpret_cast<const F4*>(row + f);
+        } else {
+          v[r][k] = F4{f < n_floats ? row[f] : 0.0f, f + 1 < n_floats ? row[f + 1] : 0.0f,
+                       f + 2 < n_floats ? row[f + 2] : 0.0f, 0.0f};
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowBatch; ++r) {
+#pragma unroll
+      for (int k = 0; k < kTileVecs; ++k) {
+        acc[k][0] = fmaf(v[r][k].x, beta[r], acc[k][0]);
+        acc[k][1] = fmaf(v[r][k].y, beta[r], acc[k][1]);
+        acc[k][2] = fmaf(v[r][k].z, beta[r], acc[k][2]);
+        acc[k][3] = fmaf(v[r][k].w, beta[r], acc[k][3]);
       }
     }
   }
@@ -195,11 +213,11 @@ hipError_t launch_resize_area(const float* src, int sh, int sw, int batch, float
       hipLaunchKernelGGL(kern, tgrid, dim3(kTileThreads), 0, st, src, dst, sh, sw, dh, dw, scale_y, scale_x);
     };
     if (scale_x <= 4.0) {
-      tiled(resize_area_tiled_kernel<256>, 256);
+      tiled(resize_area_tiled_kernel<256, 1>, 256);
     } else if (scale_x <= 8.0) {
-      tiled(resize_area_tiled_kernel<128>, 128);
+      tiled(resize_area_tiled_kernel<128, 2>, 128);
     } else {
-      tiled(resize_area_tiled_kernel<64>, 64);
+      tiled(resize_area_tiled_kernel<64, 4>, 64);
     }
     return hipGetLastError();
   }

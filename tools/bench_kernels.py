@@ -114,7 +114,7 @@ def main():
             out.data_ptr(), out.data_ptr() + 4 * n, out.data_ptr() + 8 * n, n, back.data_ptr())))
         del back
     if "t" in todo:  # preview / thumbnail producers: 24 MP -> 512 x 341 and -> 1 MP
-        for name, (dw, dh) in (("512px thumbnail", (512, 341)), ("1 MP preview", (1224, 816))):
+        for name, (dw, dh) in (("512px thumbnail", (512, 341)), ("1 MP preview", (1224, 816)), ("4 MP preview", (2449, 1632))):
             small = torch.empty((B, dh, dw, 3), dtype=torch.float32, device=dev)
             report(f"t  area resize -> {name}", H, W, B, 12 + 12 * dw * dh / (H * W),
                    *timeit(lambda: ctx.resize_area(img.data_ptr(), H, W, B, small.data_ptr(), dh, dw)))
