@@ -18,6 +18,12 @@ namespace ss {
 
 constexpr int PCT_BINS = 1024;
 constexpr int PCT_TARGETS = 4;
+#ifndef SS_PCT_SAMPLE_BLOCKS
+#define SS_PCT_SAMPLE_BLOCKS 4096u
+#endif
+#ifndef SS_PCT_REFINE_BLOCKS
+#define SS_PCT_REFINE_BLOCKS 2048u
+#endif
 constexpr int PCT_HISTS_PER_IMAGE = 3 + 3 * PCT_TARGETS + 3 * PCT_TARGETS;  // level 1, 2, 3
 
 size_t percentile_samples_bytes(int batch, int64_t n) { return (size_t)batch * 3 * (size_t)n * sizeof(uint32_t); }
@@ -41,19 +47,34 @@ __global__ __launch_bounds__(256) void pct_sample_kernel(const float* __restrict
   __syncthreads();
   const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * height * width * 3);
   uint32_t* smp = samples + (size_t)img * 3 * n;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t sy = i / ws, sx = i - sy * ws;
-    const F3 v = s[(sy * step) * (uint32_t)width + sx * step];
-    // clip to [0,1]; "+ 0.0f" turns a -0.0 that survives the clip into +0.0 so keys stay monotone
-    const uint32_t k0 = __float_as_uint(clamp01(v.x) + 0.0f);
-    const uint32_t k1 = __float_as_uint(clamp01(v.y) + 0.0f);
-    const uint32_t k2 = __float_as_uint(clamp01(v.z) + 0.0f);
-    smp[i] = k0;
-    smp[n + i] = k1;
-    smp[2 * (size_t)n + i] = k2;
-    atomicAdd(&h[k0 >> 20], 1u);
-    atomicAdd(&h[PCT_BINS + (k1 >> 20)], 1u);
-    atomicAdd(&h[2 * PCT_BINS + (k2 >> 20)], 1u);
+  // four samples per trip: the gathers (one 12-byte load per sample, 9 or more pixels apart) are all issued before
+  // the first key is binned
+  constexpr int kGather = 4;
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += kGather * stride) {
+    F3 v[kGather];
+#pragma unroll
+    for (int j = 0; j < kGather; ++j) {
+      const uint32_t i = i0 + j * stride;
+      const uint32_t ii = i < n ? i : i0;  // (past the end: reload the first one, not used)
+      const uint32_t sy = ii / ws, sx = ii - sy * ws;
+      v[j] = s[(sy * step) * (uint32_t)width + sx * step];
+    }
+#pragma unroll
+    for (int j = 0; j < kGather; ++j) {
+      const uint32_t i = i0 + j * stride;
+      if (i >= n) break;
+      // clip to [0,1]; "+ 0.0f" turns a -0.0 that survives the clip into +0.0 so keys stay monotone
+      const uint32_t k0 = __float_as_uint(clamp01(v[j].x) + 0.0f);
+      const uint32_t k1 = __float_as_uint(clamp01(v[j].y) + 0.0f);
+      const uint32_t k2 = __float_as_uint(clamp01(v[j].z) + 0.0f);
+      smp[i] = k0;
+      smp[n + i] = k1;
+      smp[2 * (size_t)n + i] = k2;
+      atomicAdd(&h[k0 >> 20], 1u);
+      atomicAdd(&h[PCT_BINS + (k1 >> 20)], 1u);
+      atomicAdd(&h[2 * PCT_BINS + (k2 >> 20)], 1u);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * PCT_BINS; i += 256) {
@@ -76,16 +97,39 @@ __global__ __launch_bounds__(256) void pct_refine_kernel(const uint32_t* __restr
   constexpr int SHIFT_MATCH = LEVEL == 2 ? 20 : 10;
   constexpr int SHIFT_DIGIT = LEVEL == 2 ? 10 : 0;
   const uint32_t* smp = samples + (size_t)img * 3 * n;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  uint32_t want[3 * PCT_TARGETS];
+#pragma unroll
+  for (int j = 0; j < 3 * PCT_TARGETS; ++j) want[j] = prefix[j] >> SHIFT_MATCH;
+  auto bin = [&](int c, uint32_t k) {
+    const uint32_t digit = (k >> SHIFT_DIGIT) & (PCT_BINS - 1);
+#pragma unroll
+    for (int t = 0; t < PCT_TARGETS; ++t) {
+      if ((k >> SHIFT_MATCH) == want[c * PCT_TARGETS + t]) atomicAdd(&h[(c * PCT_TARGETS + t) * PCT_BINS + digit], 1u);
+    }
+  };
+  // four keys per lane and channel in one 16-byte load, the three channels' loads issued together: with the
+  // 48 KB of histograms limiting a CU to three workgroups, one key per load left the memory pipe nearly empty
+  struct __attribute__((aligned(4))) K4 {
+    uint32_t x, y, z, w;
+  };
+  const uint32_t n4 = n / 4;
+  for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+    K4 k[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) k[c] = *reinterpret_cast<const K4*>(smp + (size_t)c * n + 4 * (size_t)q);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const uint32_t k = smp[(size_t)c * n + i];
-      const uint32_t digit = (k >> SHIFT_DIGIT) & (PCT_BINS - 1);
+      bin(c, k[c].x);
+      bin(c, k[c].y);
+      bin(c, k[c].z);
+      bin(c, k[c].w);
+    }
+  }
+  if (blockIdx.x == 0) {
+    const uint32_t i = n4 * 4 + threadIdx.x;
+    if (i < n) {
 #pragma unroll
-      for (int t = 0; t < PCT_TARGETS; ++t) {
-        if ((k >> SHIFT_MATCH) == (prefix[c * PCT_TARGETS + t] >> SHIFT_MATCH))
-          atomicAdd(&h[(c * PCT_TARGETS + t) * PCT_BINS + digit], 1u);
-      }
+      for (int c = 0; c < 3; ++c) bin(c, smp[(size_t)c * n + i]);
     }
   }
   __syncthreads();
@@ -254,13 +298,21 @@ hipError_t launch_negative_params(const float* src, int height, int width, int b
   unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
   if (blocks < 1) blocks = 1;
   if (blocks > 512) blocks = 512;
-  const dim3 grid(blocks, batch);
+  // Every workgroup clears and flushes its own LDS histograms (3 K words when sampling, 12 K when refining): with
+  // many images in the batch, fewer and longer workgroups per image keep that fixed cost small against the
+  // samples a workgroup handles, and the batch still fills the GPU.
+  auto per_image = [&](unsigned total_target, unsigned at_least) {
+    unsigned b = total_target / (unsigned)batch;
+    if (b < at_least) b = at_least;
+    return b < blocks ? b : blocks;
+  };
+  const dim3 grid(per_image(SS_PCT_SAMPLE_BLOCKS, 16), batch), grid_refine(per_image(SS_PCT_REFINE_BLOCKS, 4), batch);
   hipLaunchKernelGGL(pct_sample_kernel, grid, dim3(256), 0, st, src, height, width, step, ws, (uint32_t)n, w.samples,
                      w.hist);
   hipLaunchKernelGGL(pct_select_kernel<1>, dim3(batch), dim3(256), 0, st, w.hist, w.state, R);
-  hipLaunchKernelGGL(pct_refine_kernel<2>, grid, dim3(256), 0, st, w.samples, (uint32_t)n, w.state, w.hist);
+  hipLaunchKernelGGL(pct_refine_kernel<2>, grid_refine, dim3(256), 0, st, w.samples, (uint32_t)n, w.state, w.hist);
   hipLaunchKernelGGL(pct_select_kernel<2>, dim3(batch), dim3(256), 0, st, w.hist, w.state, R);
-  hipLaunchKernelGGL(pct_refine_kernel<3>, grid, dim3(256), 0, st, w.samples, (uint32_t)n, w.state, w.hist);
+  hipLaunchKernelGGL(pct_refine_kernel<3>, grid_refine, dim3(256), 0, st, w.samples, (uint32_t)n, w.state, w.hist);
   hipLaunchKernelGGL(pct_final_kernel, dim3(batch), dim3(256), 0, st, w.hist, w.state, R, params, detail);
   return hipGetLastError();
 }

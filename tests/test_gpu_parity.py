@@ -123,7 +123,10 @@ def _negative_params(images, low, high, legacy):
 
 
 @pytest.mark.parametrize("shape,low,high", [((96, 128), 0.05, 0.995), ((1100, 1300), 0.05, 0.995),
-                                            ((700, 1000), 0.005, 0.995), ((64, 64), 0.0, 1.0), ((1, 1), 0.05, 0.995)])
+                                            ((700, 1000), 0.005, 0.995), ((64, 64), 0.0, 1.0), ((1, 1), 0.05, 0.995),
+                                            # sample counts 3, 6, 35, 5063: no multiple of the 4 keys a lane loads at once
+                                            ((1, 3), 0.05, 0.995), ((2, 3), 0.3, 0.7), ((5, 7), 0.05, 0.995),
+                                            ((61, 83), 0.01, 0.9), ((1001, 1003), 0.05, 0.995)])
 @pytest.mark.parametrize("legacy", [True, False])
 def test_percentiles_are_exact_order_statistics(shape, low, high, legacy):
     imgs = np.stack([inputs.negative_image(31, *shape), inputs.wide_image(32, *shape)])
