@@ -165,7 +165,9 @@ typedef struct ss_host_opts {
 } ss_host_opts;
 
 /* Same on host buffers (synchronous): pinned staging, async upload, kernels, async download.
- * opts may be NULL (no automatic percentiles, no Lab detection). */
+ * opts may be NULL (no automatic percentiles, no Lab detection).  Page-locked buffers (ss_host_alloc) are read and
+ * written by the copy engines directly, and a batch of them is pipelined image by image: upload of image i + 1,
+ * kernels of image i and download of image i - 1 at once, same results (SS_HOST_PIPELINE=0 disables it). */
 int ss_chain_run_host(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_host, void* dst_host,
                       ss_host_opts* opts);
 

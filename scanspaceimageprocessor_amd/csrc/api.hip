@@ -46,6 +46,9 @@ struct ss_ctx {
   void* host_neg = nullptr;
   size_t host_src_bytes = 0, host_dst_bytes = 0;
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  // batch pipeline of the host path: upload and download streams beside `stream`, a small ring of events
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[4] = {nullptr, nullptr, nullptr, nullptr}, ev_k[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -424,6 +427,12 @@ void ss_ctx_destroy(ss_ctx* c) {
     if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
     if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
   }
+  for (int i = 0; i < 4; ++i) {
+    if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+    if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]);
+  }
+  if (c->s_in) (void)hipStreamDestroy(c->s_in);
+  if (c->s_out) (void)hipStreamDestroy(c->s_out);
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -708,6 +717,79 @@ int ss_download(ss_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes) 
   return copy_d2h(c, dst_host, src_dev, bytes);
 }
 
+namespace {
+
+constexpr int kPipeEvents = 4;
+
+int ensure_pipeline(ss_ctx* c) {
+  if (!c->s_in) SS_HIP(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+  if (!c->s_out) SS_HIP(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+  for (int i = 0; i < kPipeEvents; ++i) {
+    if (!c->ev_in[i]) SS_HIP(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+    if (!c->ev_k[i]) SS_HIP(c, hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
+  }
+  return SS_OK;
+}
+
+bool host_pipeline_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SS_HOST_PIPELINE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// A batch in page-locked host memory, image by image: the upload of image i + 1, the kernels of image i and the
+// download of image i - 1 run on three streams at once (PCIe carries both directions together), ordered by
+// events.  The device buffers hold the whole batch, so no image waits for another's buffer.  Images are
+// independent in every stage (the negative percentiles are per image, editingTools.py:324-330).
+int run_host_pipelined(ss_ctx* c, const ss_chain_desc* d, const float* src_host, void* dst_host,
+                       const ss_host_opts* opts) {
+  int rc = ensure_pipeline(c);
+  if (rc) return rc;
+  const size_t in_img = (size_t)d->height * d->width * 12;
+  const size_t out_img = (size_t)d->height * d->width * out_bytes_per_px(d->out_kind);
+  const bool neg_auto = opts && opts->neg_auto && d->neg_enabled && !d->neg_params_dev;
+  auto step = [&](int i) -> int {
+    const int slot = i % kPipeEvents;
+    const float* src_i = (const float*)((const char*)c->host_src + (size_t)i * in_img);
+    void* dst_i = (char*)c->host_dst + (size_t)i * out_img;
+    SS_HIP(c, hipMemcpyAsync((void*)src_i, (const char*)src_host + (size_t)i * in_img, in_img, hipMemcpyHostToDevice,
+                             c->s_in));
+    SS_HIP(c, hipEventRecord(c->ev_in[slot], c->s_in));
+    SS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+    ss_chain_desc dd = *d;
+    dd.batch = 1;
+    if (dd.gain0_dev) dd.gain0_dev += i;
+    if (neg_auto) {
+      float* p = (float*)c->host_neg + (size_t)i * SS_NEG_PARAM_STRIDE;
+      int r = ss_negative_params(c, src_i, d->height, d->width, 1, opts->neg_low_percentile, opts->neg_high_percentile,
+                                 opts->legacy_numpy, p, nullptr);
+      if (r) return r;
+      dd.neg_params_dev = p;
+    } else if (dd.neg_params_dev) {
+      dd.neg_params_dev += (size_t)i * SS_NEG_PARAM_STRIDE;
+    }
+    int r = ss_chain_run(c, &dd, src_i, dst_i);
+    if (r) return r;
+    SS_HIP(c, hipEventRecord(c->ev_k[slot], c->stream));
+    SS_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_k[slot], 0));
+    SS_HIP(c, hipMemcpyAsync((char*)dst_host + (size_t)i * out_img, dst_i, out_img, hipMemcpyDeviceToHost, c->s_out));
+    return SS_OK;
+  };
+  for (int i = 0; i < d->batch && rc == SS_OK; ++i) rc = step(i);
+  // success or not, nothing may still be reading or writing the caller's buffers on return
+  const hipError_t e0 = hipStreamSynchronize(c->s_in), e1 = hipStreamSynchronize(c->stream),
+                   e2 = hipStreamSynchronize(c->s_out);
+  if (rc) return rc;
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess)
+    return fail(c, SS_ERR_HIP, "host pipeline failed: %s",
+                hipGetErrorString(e0 != hipSuccess ? e0 : e1 != hipSuccess ? e1 : e2));
+  return SS_OK;
+}
+
+}  // namespace
+
 int ss_chain_run_host(ss_ctx* c, const ss_chain_desc* d, const float* src_host, void* dst_host, ss_host_opts* opts) {
   int rc = check_ctx(c);
   if (rc) return rc;
@@ -721,10 +803,15 @@ int ss_chain_run_host(ss_ctx* c, const ss_chain_desc* d, const float* src_host, 
   if (rc) return rc;
   rc = grow(c, &c->host_dst, &c->host_dst_bytes, out_bytes);
   if (rc) return rc;
+  if (!c->host_neg) SS_HIP(c, hipMalloc(&c->host_neg, 65536 * SS_NEG_PARAM_STRIDE * sizeof(float)));
+  if (d->batch > 1 && !(opts && opts->lab_auto) && in_bytes / d->batch >= ((size_t)1 << 20) && host_pipeline_enabled() &&
+      is_pinned_host(src_host) && is_pinned_host(dst_host)) {
+    if (opts) opts->lab_detected = 0;
+    return run_host_pipelined(c, d, src_host, dst_host, opts);
+  }
   rc = copy_h2d(c, c->host_src, src_host, in_bytes);
   if (rc) return rc;
   ss_chain_desc dd = *d;
-  if (!c->host_neg) SS_HIP(c, hipMalloc(&c->host_neg, 65536 * SS_NEG_PARAM_STRIDE * sizeof(float)));
   if (opts && opts->neg_auto && d->neg_enabled && !d->neg_params_dev) {
     rc = ss_negative_params(c, (const float*)c->host_src, d->height, d->width, d->batch, opts->neg_low_percentile,
                             opts->neg_high_percentile, opts->legacy_numpy, (float*)c->host_neg, nullptr);

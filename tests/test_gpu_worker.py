@@ -245,3 +245,34 @@ def test_reused_output_buffers_give_the_same_images():
     e0, p0 = plain.process_array(big, "a.nef")
     np.testing.assert_array_equal(e0, e1)
     np.testing.assert_array_equal(p0, p1)
+
+
+def test_batches_in_page_locked_memory_are_pipelined_image_by_image():
+    """A batch handed over in page-locked buffers goes through upload / kernels / download image by image on
+    three streams; the result must be bit for bit what one call per image gives (pageable buffers, one image each:
+    the unpipelined path), automatic negative percentiles and sharpening included."""
+    from scanspaceimageprocessor_amd import default_context
+    from scanspaceimageprocessor_amd.chain import make_desc
+
+    ctx = default_context()
+    b, h, w = 5, 520, 700   # 4.4 MB per image
+    imgs = np.stack([inputs.GENERATORS["negative"](200 + i, h, w) for i in range(b)])
+    M_T, M_R = inputs.synthetic_swatches()
+    from scanspaceimageprocessor_amd.colour_fit import matrix_colour_correction
+
+    ccm = matrix_colour_correction(M_T, M_R)
+    for kw, out_kind, dtype in ((dict(neg=True, ccm=ccm, gains=[1.1], usm=(40.0, 2.0, 0.0), final_clip=True), "u16", np.uint16),
+                                (dict(ccm=ccm, gains=[0.9], sh=(0.3, -0.4, 7.0), final_clip=True), "f32", np.float32)):
+        neg_auto = bool(kw.get("neg"))
+        pin_in = ctx.pinned_empty(imgs.shape, np.float32)
+        pin_in[...] = imgs
+        pin_out = ctx.pinned_empty(imgs.shape, dtype)
+        pin_out[...] = 0
+        got, _ = ctx.chain_run_host(make_desc(h, w, b, out=out_kind, **kw), pin_in, neg_auto=neg_auto, out=pin_out)
+        assert got is pin_out
+        for i in range(b):
+            want, _ = ctx.chain_run_host(make_desc(h, w, 1, out=out_kind, **kw), imgs[i], neg_auto=neg_auto)
+            np.testing.assert_array_equal(got[i], want)
+        # and the same batch from pageable memory (whole-batch upload, one launch, whole-batch download)
+        whole, _ = ctx.chain_run_host(make_desc(h, w, b, out=out_kind, **kw), imgs, neg_auto=neg_auto)
+        np.testing.assert_array_equal(whole, got)
