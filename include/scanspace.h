@@ -289,6 +289,13 @@ int ss_host_free(ss_ctx* ctx, void* host); /* ctx may be NULL when the context i
 /* Synchronous copies (through the context's pinned staging ring unless the host side is page-locked). */
 int ss_upload(ss_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int ss_download(ss_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+/* Asynchronous copies between PAGE-LOCKED host memory and the device, queued on the context's stream in order
+ * with its kernels (the device-resident use of the reference's load -> correct -> encode sequence,
+ * imageProcessorWorker.py:839-923, without a host stall per step); ss_ctx_sync waits for them.  The host buffer
+ * must stay valid and untouched until then.  Pageable memory is refused (SS_ERR_INVALID): it cannot be copied
+ * without the calling thread staging it. */
+int ss_upload_async(ss_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int ss_download_async(ss_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 
 /* ---- timing (HIP events on the context's stream) ------------------------------------------ */
 

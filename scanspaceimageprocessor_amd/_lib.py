@@ -117,6 +117,8 @@ SIGNATURES = {
     "ss_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ss_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ss_download_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ss_timer_start": (C.c_int, [C.c_void_p]),
     "ss_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }
@@ -265,6 +267,17 @@ class Context:
     def download(self, arr, src_dev):
         assert arr.flags.c_contiguous and arr.flags.writeable
         self.check(self.lib.ss_download(self.handle, arr.ctypes.data_as(C.c_void_p), C.c_void_p(src_dev), arr.nbytes))
+
+    def upload_async(self, dst_dev, arr):
+        """Queue the upload of a page-locked array (``pinned_empty``) on the context's stream; keep ``arr`` alive and
+        unchanged until ``sync``."""
+        assert arr.flags.c_contiguous
+        self.check(self.lib.ss_upload_async(self.handle, C.c_void_p(dst_dev), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def download_async(self, arr, src_dev):
+        """Queue the download into a page-locked array on the context's stream; read ``arr`` after ``sync``."""
+        assert arr.flags.c_contiguous and arr.flags.writeable
+        self.check(self.lib.ss_download_async(self.handle, arr.ctypes.data_as(C.c_void_p), C.c_void_p(src_dev), arr.nbytes))
 
     # -- entry points on device pointers
     def chain_run(self, desc, src_dev, dst_dev):

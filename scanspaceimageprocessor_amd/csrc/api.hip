@@ -717,6 +717,28 @@ int ss_download(ss_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes) 
   return copy_d2h(c, dst_host, src_dev, bytes);
 }
 
+int ss_upload_async(ss_ctx* c, void* dst_dev, const void* src_host, uint64_t bytes) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!dst_dev || !src_host) return fail(c, SS_ERR_INVALID, "NULL pointer");
+  if (bytes == 0) return SS_OK;
+  if (!is_pinned_host(src_host))
+    return fail(c, SS_ERR_INVALID, "ss_upload_async needs page-locked host memory (ss_host_alloc); use ss_upload");
+  SS_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+  return SS_OK;
+}
+
+int ss_download_async(ss_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!dst_host || !src_dev) return fail(c, SS_ERR_INVALID, "NULL pointer");
+  if (bytes == 0) return SS_OK;
+  if (!is_pinned_host(dst_host))
+    return fail(c, SS_ERR_INVALID, "ss_download_async needs page-locked host memory (ss_host_alloc); use ss_download");
+  SS_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  return SS_OK;
+}
+
 namespace {
 
 constexpr int kPipeEvents = 4;

@@ -276,3 +276,36 @@ def test_batches_in_page_locked_memory_are_pipelined_image_by_image():
         # and the same batch from pageable memory (whole-batch upload, one launch, whole-batch download)
         whole, _ = ctx.chain_run_host(make_desc(h, w, b, out=out_kind, **kw), imgs, neg_auto=neg_auto)
         np.testing.assert_array_equal(whole, got)
+
+
+def test_asynchronous_copies_of_page_locked_buffers_run_in_stream_order():
+    """upload_async -> chain_run -> download_async -> sync: nothing stalls the host in between, the copies are
+    ordered with the kernels on the context's stream; pageable memory is refused."""
+    from scanspaceimageprocessor_amd import _lib, default_context
+    from scanspaceimageprocessor_amd.chain import make_desc
+
+    ctx = default_context()
+    h, w = 300, 500
+    img = inputs.linear_image(321, h, w)
+    pin_in = ctx.pinned_empty(img.shape, np.float32)
+    pin_in[...] = img
+    pin_out = ctx.pinned_empty(img.shape, np.uint16)
+    pin_out[...] = 0
+    src, dst = ctx.malloc(img.nbytes), ctx.malloc(pin_out.nbytes)
+    try:
+        desc = make_desc(h, w, 1, gains=[1.2], final_clip=True, out="u16")
+        ctx.upload_async(src, pin_in)
+        ctx.chain_run(desc, src, dst)
+        ctx.download_async(pin_out, dst)
+        ctx.sync()
+        want, _ = ctx.chain_run_host(desc, img)
+        np.testing.assert_array_equal(pin_out, want)
+        with pytest.raises(_lib.ScanSpaceError) as e:
+            ctx.upload_async(src, img)            # numpy's own (pageable) memory
+        assert e.value.code == _lib.SS_ERR_INVALID
+        with pytest.raises(_lib.ScanSpaceError):
+            ctx.download_async(np.empty_like(want), dst)
+        ctx.sync()
+    finally:
+        ctx.free(src)
+        ctx.free(dst)
