@@ -171,6 +171,18 @@ typedef struct ss_host_opts {
 int ss_chain_run_host(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_host, void* dst_host,
                       ss_host_opts* opts);
 
+/* ss_chain_run for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Same arguments, kernels and results as ss_chain_run,
+ * but the unsharp-mask kernel's work-queue counters (eight per-XCD tickets) live in a 256-byte static device
+ * array of the library instead of memory the context allocated, and the call itself performs no hipMalloc,
+ * hipFree or other allocating call.  Every GPU holds one copy of that array for the life of the process and
+ * every call on a GPU shares it (the counters are cleared in stream order before each launch): calls that
+ * overlap on one GPU - two contexts, two streams - race on it; order them on one stream.
+ * Limits: the combination "unsharp mask behind a colour correction of more than 3 terms" needs a staging image
+ * per image of the batch and is refused (SS_ERR_UNSUPPORTED: use ss_chain_run); the batch may hold at most
+ * 2^31 - 1 tiles of 128 x 24 pixels.  Asynchronous. */
+int ss_chain_run_static(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev);
+
 /* ---- negative film mode: per-channel percentiles ------------------------------------------ */
 
 /* Per-image detail of the percentile search (all exact order statistics of the strided sample). */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ss_last_error": (C.c_char_p, [C.c_void_p]),
     "ss_version": (C.c_char_p, []),
     "ss_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
+    "ss_chain_run_static": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
     "ss_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p, C.POINTER(HostOpts)]),
     "ss_percentile_rank": (C.c_int, [C.c_int64, C.c_double, C.c_int, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -282,6 +283,11 @@ class Context:
     # -- entry points on device pointers
     def chain_run(self, desc, src_dev, dst_dev):
         self.check(self.lib.ss_chain_run(self.handle, C.byref(desc), C.c_void_p(src_dev), C.c_void_p(dst_dev)))
+
+    def chain_run_static(self, desc, src_dev, dst_dev):
+        """``chain_run`` without any allocation inside the call (work-queue counters in the library's static device
+        scratch): for callers under graph capture.  Calls on one GPU must not overlap."""
+        self.check(self.lib.ss_chain_run_static(self.handle, C.byref(desc), C.c_void_p(src_dev), C.c_void_p(dst_dev)))
 
     def negative_params(self, src_dev, height, width, batch, low, high, legacy_numpy, params_dev, detail_dev=None):
         self.check(self.lib.ss_negative_params(self.handle, C.c_void_p(src_dev), height, width, batch,

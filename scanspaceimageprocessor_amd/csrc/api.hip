@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -34,6 +35,7 @@ struct ss_ctx {
   void* ws_small = nullptr;  // histograms, select state, partials
   size_t ws_small_bytes = 0;
   uint32_t* usm_ticket = nullptr;  // per-XCD segment counters of the unsharp-mask kernel's work queue
+  uint32_t* static_ticket = nullptr;  // the same counters inside this GPU's copy of `scratch` (ss_chain_run_static)
   void* ws_stage = nullptr;        // float32 images between the two passes of a staged chain
   size_t ws_stage_bytes = 0;
   void* ws_mask = nullptr;         // labels and areas of the region masking
@@ -51,7 +53,34 @@ struct ss_ctx {
   hipEvent_t ev_in[4] = {nullptr, nullptr, nullptr, nullptr}, ev_k[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
+// Scratch of the allocation-free entry point (ss_chain_run_static): the eight per-XCD segment counters of the
+// unsharp-mask kernel's work queue, in the code object's own device memory instead of a hipMalloc'd buffer.
+// 256 bytes; every GPU the library runs on holds its own copy at its own address until the process ends.
+// In host code this name is only a handle for hipGetSymbolAddress: kernels, memsets and copies get the
+// per-device address resolved below, never the name.
+static __device__ __align__(256) uint32_t scratch[64];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+uint32_t* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on `device`, which must be the current device.  Resolved once per device.
+hipError_t resolve_scratch(int device, uint32_t** out) {
+  *out = nullptr;
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = static_cast<uint32_t*>(p);
+  }
+  *out = g_scratch_ptr[device];
+  return hipSuccess;
+}
 
 int fail(ss_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -403,6 +432,12 @@ int ss_ctx_create(int device, ss_ctx** out_ctx) {
     delete c;
     return fail(nullptr, SS_ERR_NOMEM, "hipMalloc of the work-queue counter failed: %s", hipGetErrorString(e));
   }
+  e = resolve_scratch(device, &c->static_ticket);  // (device is current)
+  if (e != hipSuccess) {
+    ss_ctx_destroy(c);
+    return fail(nullptr, SS_ERR_HIP, "hipGetSymbolAddress of the static scratch failed on device %d: %s", device,
+                hipGetErrorString(e));
+  }
   if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
     ss_ctx_destroy(c);
     return fail(nullptr, SS_ERR_HIP, "hipEventCreate failed");
@@ -468,6 +503,34 @@ int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* 
     return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
   if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3) return run_staged_usm(c, d, P, src_dev, dst_dev);
   hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->usm_ticket, c->stream)
+                       : launch_chain(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
+int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!src_dev || !dst_dev) return fail(c, SS_ERR_INVALID, "src_dev and dst_dev must not be NULL");
+  ChainParams P;
+  rc = build_params(c, d, &P);
+  if (rc) return rc;
+  if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
+    return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
+  if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3)
+    return fail(c, SS_ERR_UNSUPPORTED,
+                "an unsharp mask behind a %d-term colour correction needs a float32 staging image per image of the "
+                "batch, beyond the 256-byte static scratch of ss_chain_run_static: use ss_chain_run",
+                P.ccm_terms);
+  if (P.usm) {
+    // the work queue's counters are 32-bit tickets over the segments of the whole batch
+    const int64_t tiles = (int64_t)((d->width + 127) / 128) * ((d->height + 23) / 24) * d->batch;
+    if (tiles > INT32_MAX)
+      return fail(c, SS_ERR_UNSUPPORTED, "%lld tiles exceed the 2^31 - 1 the static work-queue counters can hand out",
+                  (long long)tiles);
+  }
+  if (!c->static_ticket) return fail(c, SS_ERR_HIP, "the static scratch was not resolved on device %d", c->device);
+  hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->static_ticket, c->stream)
                        : launch_chain(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream);
   if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return SS_OK;
