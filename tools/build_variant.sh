@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../scanspaceimageprocessor_amd/csrc"
 name=$1; shift
 mkdir -p ../variants build/$name
-for f in chain usm stats resize mask api; do
+for f in chain usm stats resize mask lab api; do
   if [[ " ${FILES:-usm} " == *" $f "* ]] || [ ! -f build/$f.o ]; then
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -fno-slp-vectorize "$@" -c $f.hip -o build/$name/$f.o &
   else
