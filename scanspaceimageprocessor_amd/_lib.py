@@ -134,6 +134,32 @@ class ScanSpaceError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7)
+    and ask for it by the unversioned file name: loaded AFTER the system runtime this library links to, that is a
+    second runtime in the process, whose initialisation finds no GPU ("No HIP GPUs are available").  Loaded
+    first, it satisfies this library's dependency by soname and both share it.  So when torch is installed and
+    not yet imported, its runtime is loaded here, before the library.  SCANSPACE_SYSTEM_HIP=1 keeps the system
+    runtime (for processes that never import torch)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("SCANSPACE_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # the system runtime is used; importing torch later in this process may then fail
+
+
 def load_library():
     """Load libscanspace_hip.so (built in-tree by ``__graft_entry__.build()``) and type its symbols."""
     global _lib
@@ -143,6 +169,7 @@ def load_library():
                 raise ImportError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            _share_torch_hip_runtime()
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

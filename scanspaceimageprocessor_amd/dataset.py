@@ -54,40 +54,76 @@ def gather_brightness(local, n_images: int, group=None):
     return torch.cat(pieces)
 
 
-class ExposureNormaliser:
-    """Device-side dataset exposure normalisation for one rank's shard.
+class HipExposureOps:
+    """The two device steps of dataset exposure normalisation on one context's GPU and stream
+    (``ss_exposure_stats``, ``ss_exposure_multipliers``) over torch CUDA tensors."""
 
-    ``run`` = per-thumbnail masked-luminance statistics (HIP) -> all-gather (RCCL, if more than one
-    rank) -> multipliers for the local shard (HIP), written to ``self.gains`` (device float32,
-    one per local image) which ``ss_chain_desc.gain0_dev`` consumes.
+    def __init__(self, ctx):
+        import torch
+
+        self.ctx = ctx
+        self.device = torch.device("cuda", ctx.device)
+
+    def empty(self, count):
+        import torch
+
+        return torch.empty((count,), dtype=torch.float32, device=self.device)
+
+    def stats(self, thumbs_ptr, thumb_h, thumb_w, count, shadow_limit, highlight_limit, brightness):
+        self.ctx.exposure_stats(thumbs_ptr, thumb_h, thumb_w, count, shadow_limit, highlight_limit, None,
+                                brightness.data_ptr())
+
+    def multipliers(self, brightness_all, n_images, chart_index, first, count, gains):
+        self.ctx.exposure_multipliers(brightness_all.data_ptr(), n_images, chart_index, first, count, gains.data_ptr())
+
+    def stream_scope(self):
+        """Context manager that makes the context's stream torch's current stream: the collective must follow the
+        statistics kernel and precede the multiplier kernel, whatever torch's current stream is."""
+        import torch
+
+        return torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream, device=self.device))
+
+
+class ExposureNormaliser:
+    """Dataset exposure normalisation for one rank's shard.
+
+    ``run`` = per-thumbnail masked-luminance statistics -> all-gather (if more than one rank) -> multipliers
+    for the local shard, written to ``self.gains`` (one float32 per local image) which
+    ``ss_chain_desc.gain0_dev`` consumes.
+
+    ``ops`` carries the two compute steps and the tensors (default: ``HipExposureOps(ctx)``, the HIP kernels on
+    the context's stream); ``gather(local, n_images)`` returns the brightness of all images in image order
+    (default: ``gather_brightness`` over ``group``, RCCL on GPU tensors).  The shard arithmetic, the order of the
+    steps and the ranges handed to them are the same whatever the two are, so multi-process CPU tests drive this
+    very class with host-side ``ops`` over gloo.
     """
 
     def __init__(self, ctx, n_images: int, rank: int = 0, world: int = 1, shadow_limit: float = 0.06,
-                 highlight_limit: float = 0.96, chart_index: Optional[int] = None, group=None):
-        import torch
-
+                 highlight_limit: float = 0.96, chart_index: Optional[int] = None, group=None, gather=None, ops=None):
         self.ctx, self.n_images, self.rank, self.world, self.group = ctx, n_images, rank, world, group
         self.first, self.count = shard_range(n_images, rank, world)
         self.shadow_limit, self.highlight_limit, self.chart_index = shadow_limit, highlight_limit, chart_index
-        dev = torch.device("cuda", ctx.device)
-        self.brightness = torch.empty((self.count,), dtype=torch.float32, device=dev)
-        self.gains = torch.empty((self.count,), dtype=torch.float32, device=dev)
+        if chart_index is not None and not (0 <= chart_index < n_images):
+            raise ValueError(f"chart_index {chart_index} outside the dataset of {n_images} images")
+        self.ops = ops if ops is not None else HipExposureOps(ctx)
+        self.gather = gather if gather is not None else (lambda local, n: gather_brightness(local, n, self.group))
+        self.brightness = self.ops.empty(self.count)
+        self.gains = self.ops.empty(self.count)
         self.brightness_all = self.brightness
 
-    def run(self, thumbs_ptr: int, thumb_h: int, thumb_w: int):
-        self.ctx.exposure_stats(thumbs_ptr, thumb_h, thumb_w, self.count, self.shadow_limit, self.highlight_limit,
-                                None, self.brightness.data_ptr())
+    def run(self, thumbs_ptr, thumb_h: int, thumb_w: int):
+        """``thumbs_ptr``: this rank's ``count`` thumbnails, ``[count][thumb_h][thumb_w][3]`` float32 (a device
+        address for the HIP ops)."""
+        self.ops.stats(thumbs_ptr, thumb_h, thumb_w, self.count, self.shadow_limit, self.highlight_limit,
+                       self.brightness)
         if self.world > 1:
-            # the collective must follow the statistics kernel and precede the multiplier kernel: issue it on
-            # the context's stream, whatever torch's current stream is
-            import torch
-
-            with torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream, device=self.brightness.device)):
-                self.brightness_all = gather_brightness(self.brightness, self.n_images, self.group)
+            with self.ops.stream_scope():
+                self.brightness_all = self.gather(self.brightness, self.n_images)
+            if self.brightness_all.numel() != self.n_images:
+                raise ValueError(f"gather returned {self.brightness_all.numel()} values for {self.n_images} images")
         else:
             self.brightness_all = self.brightness
-        self.ctx.exposure_multipliers(self.brightness_all.data_ptr(), self.n_images, self.chart_index,
-                                      self.first, self.count, self.gains.data_ptr())
+        self.ops.multipliers(self.brightness_all, self.n_images, self.chart_index, self.first, self.count, self.gains)
         return self.gains
 
 

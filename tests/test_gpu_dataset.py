@@ -3,6 +3,7 @@ one GPU of the test box exercises the same code the multi-GPU runs use (statisti
 on the context's own stream through an ExternalStream -> multiplier kernel)."""
 
 import os
+import socket
 
 import numpy as np
 import pytest
@@ -30,28 +31,30 @@ def test_exposure_normaliser_with_an_rccl_all_gather_on_the_context_stream():
     want_m = oc.exposure_multipliers(want_b, None)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=dev)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     try:
-        norm = ExposureNormaliser(ctx, n, 0, 1, 0.06, 0.96)
-        norm.world = 2  # take the collective branch; the group itself has one rank, so the gather is an identity
-        import scanspaceimageprocessor_amd.dataset as ds
+        # Two ranks' worth of the class on the one GPU: "rank 1 of 2" computes its own shard and receives the other
+        # shard's brightness through the gather it is given, which runs a real RCCL all-gather (one-rank group) on
+        # the context's stream for the local part.
+        other = ExposureNormaliser(ctx, n, 0, 2, 0.06, 0.96, gather=lambda local, n_images: None)
+        other.ops.stats(t.data_ptr(), h, w, other.count, 0.06, 0.96, other.brightness)
 
-        real = ds.gather_brightness
-
-        def gather_one_rank(local, n_images, group=None):
-            out = torch.empty_like(local)
-            dist.all_gather_into_tensor(out, local, group=group)  # issued on the current stream = ctx stream
+        def gather(local, n_images):
             assert torch.cuda.current_stream(dev).cuda_stream == ctx.stream
-            return out
+            out = torch.empty_like(local)
+            dist.all_gather_into_tensor(out, local)  # issued on the current stream = the context's stream
+            return torch.cat([other.brightness, out])
 
-        ds.gather_brightness = gather_one_rank
-        try:
-            for _ in range(3):
-                gains = norm.run(t.data_ptr(), h, w)
-        finally:
-            ds.gather_brightness = real
+        norm = ExposureNormaliser(ctx, n, 1, 2, 0.06, 0.96, gather=gather)
+        assert (norm.first, norm.count) == (3, 3)
+        shard = t[norm.first:norm.first + norm.count]
+        for _ in range(3):
+            gains = norm.run(shard.data_ptr(), h, w)
         ctx.sync()
-        np.testing.assert_allclose(gains.cpu().numpy(), want_m, rtol=1e-6)
+        np.testing.assert_allclose(gains.cpu().numpy(), want_m[norm.first:], rtol=1e-6)
         np.testing.assert_allclose(norm.brightness_all.cpu().numpy(), want_b, rtol=1e-6)
     finally:
         dist.destroy_process_group()
