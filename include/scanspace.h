@@ -122,6 +122,12 @@ typedef struct ss_chain_desc {
   /* 6./7. */
   int32_t final_clip; /* clip to [0,1] before encoding */
   int32_t out_kind;   /* ss_out_kind */
+
+  /* Low-order parts of the colour-correction coefficients, same layout as `ccm`: ccm[i] + ccm_lo[i] is the
+   * float64 coefficient colour.matrix_colour_correction produced.  Read only for the few pixels the kernels
+   * re-evaluate in float64 (a Lab edit that cancels a channel to almost zero); all zero when the caller has
+   * float32 coefficients only. */
+  float ccm_lo[3 * SS_MAX_CCM_TERMS];
 } ss_chain_desc;
 
 /* ---- context ----------------------------------------------------------------------------- */
@@ -171,16 +177,27 @@ typedef struct ss_host_opts {
 int ss_chain_run_host(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_host, void* dst_host,
                       ss_host_opts* opts);
 
+/* Lab edits (stages 4 and 5) that cancel one channel of a pixel to almost zero are beyond float32: the two sRGB
+ * encodes behind them amplify its rounding to several 16-bit steps, where the reference (float64 throughout,
+ * editingTools.py:367-408) has none.  The kernels recognise such pixels and record them (one bit per pixel, owned
+ * by the context), and a second kernel evaluates them again in float64 from the source pixel (float32 and 16-bit
+ * outputs; 8-bit outputs never need it).  This call reports how many pixels of the most recent ss_chain_run /
+ * ss_chain_run_static on the context were evaluated again (for a staged chain: of its last group of images).
+ * Synchronises the stream. */
+int ss_chain_requeued(ss_ctx* ctx, uint64_t* n_pixels);
+
 /* ss_chain_run for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc.  No counterpart in the reference.  Same arguments, kernels and results as ss_chain_run,
- * but the unsharp-mask kernel's work-queue counters (eight per-XCD tickets) live in a 256-byte static device
- * array of the library instead of memory the context allocated, and the call itself performs no hipMalloc,
- * hipFree or other allocating call.  Every GPU holds one copy of that array for the life of the process and
- * every call on a GPU shares it (the counters are cleared in stream order before each launch): calls that
- * overlap on one GPU - two contexts, two streams - race on it; order them on one stream.
- * Limits: the combination "unsharp mask behind a colour correction of more than 3 terms" needs a staging image
- * per image of the batch and is refused (SS_ERR_UNSUPPORTED: use ss_chain_run); the batch may hold at most
- * 2^31 - 1 tiles of 128 x 24 pixels.  Asynchronous. */
+ * but the scratch of its kernels - the unsharp-mask kernel's work-queue counters (eight per-XCD tickets) and the
+ * one-bit-per-pixel record for the float64 re-evaluation (see ss_chain_requeued) - lives in a static device array
+ * of the library (16 MiB + 512 B) instead of memory the context allocated, and the call itself performs no
+ * hipMalloc, hipFree or other allocating call.  Every GPU holds one copy of that array for the life of the process
+ * and every call on a GPU shares it (what must start at zero is cleared in stream order before each launch): calls
+ * that overlap on one GPU - two contexts, two streams - race on it; order them on one stream.
+ * Limits: a chain with a Lab edit and a float32 or 16-bit output may cover about 134 million pixels per call (the
+ * record's 16 MiB; beyond: SS_ERR_UNSUPPORTED); the combination "unsharp mask behind a colour correction of more
+ * than 3 terms" needs a staging image per image of the batch and is refused (SS_ERR_UNSUPPORTED: use
+ * ss_chain_run); the batch may hold at most 2^31 - 1 tiles of 128 x 24 pixels.  Asynchronous. */
 int ss_chain_run_static(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev);
 
 /* ---- negative film mode: per-channel percentiles ------------------------------------------ */

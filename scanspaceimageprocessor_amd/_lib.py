@@ -57,6 +57,7 @@ class ChainDesc(C.Structure):
         ("lab_io", C.c_int32),
         ("final_clip", C.c_int32),
         ("out_kind", C.c_int32),
+        ("ccm_lo", C.c_float * (3 * SS_MAX_CCM_TERMS)),
     ]
 
 
@@ -93,6 +94,7 @@ SIGNATURES = {
     "ss_version": (C.c_char_p, []),
     "ss_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
     "ss_chain_run_static": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
+    "ss_chain_requeued": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ss_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p, C.POINTER(HostOpts)]),
     "ss_percentile_rank": (C.c_int, [C.c_int64, C.c_double, C.c_int, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -315,6 +317,12 @@ class Context:
         """``chain_run`` without any allocation inside the call (work-queue counters in the library's static device
         scratch): for callers under graph capture.  Calls on one GPU must not overlap."""
         self.check(self.lib.ss_chain_run_static(self.handle, C.byref(desc), C.c_void_p(src_dev), C.c_void_p(dst_dev)))
+
+    def chain_requeued(self):
+        """Pixels the most recent chain run on this context evaluated again in float64.  Synchronises."""
+        n = C.c_uint64()
+        self.check(self.lib.ss_chain_requeued(self.handle, C.byref(n)))
+        return n.value
 
     def negative_params(self, src_dev, height, width, batch, low, high, legacy_numpy, params_dev, detail_dev=None):
         self.check(self.lib.ss_negative_params(self.handle, C.c_void_p(src_dev), height, width, batch,

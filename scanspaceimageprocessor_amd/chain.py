@@ -42,8 +42,10 @@ def make_desc(height, width, batch=1, *, neg=None, neg_params_dev=None, ccm=None
             raise ValueError(f"colour correction matrix must be (3, {terms}), got {m.shape}")
         d.ccm_kind, d.ccm_terms = int(kind), int(terms)
         flat = m.astype(np.float32).ravel()
+        low = (m.ravel() - flat.astype(np.float64)).astype(np.float32)  # ccm + ccm_lo = the float64 coefficient
         for i, v in enumerate(flat):
             d.ccm[i] = float(v)
+            d.ccm_lo[i] = float(low[i])
     gains = list(gains)
     if len(gains) > _lib.SS_MAX_GAIN_STAGES:
         raise ValueError("at most 3 gain stages")

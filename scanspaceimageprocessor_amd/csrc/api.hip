@@ -40,6 +40,9 @@ struct ss_ctx {
   size_t ws_stage_bytes = 0;
   void* ws_mask = nullptr;         // labels and areas of the region masking
   size_t ws_mask_bytes = 0;
+  void* ws_risk = nullptr;         // queue of the pixels the float64 kernel evaluates again: counters, then entries
+  size_t ws_risk_bytes = 0;
+  const uint32_t* last_risk_count = nullptr;  // re-evaluated pixels of the most recent chain launch with a record
   // host path
   void* pinned[2] = {nullptr, nullptr};
   hipEvent_t pinned_free[2] = {nullptr, nullptr};
@@ -53,12 +56,17 @@ struct ss_ctx {
   hipEvent_t ev_in[4] = {nullptr, nullptr, nullptr, nullptr}, ev_k[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
-// Scratch of the allocation-free entry point (ss_chain_run_static): the eight per-XCD segment counters of the
-// unsharp-mask kernel's work queue, in the code object's own device memory instead of a hipMalloc'd buffer.
-// 256 bytes; every GPU the library runs on holds its own copy at its own address until the process ends.
+// Scratch of the allocation-free entry point (ss_chain_run_static), in the code object's own device memory instead
+// of hipMalloc'd buffers: the eight per-XCD segment counters of the unsharp-mask kernel's work queue, and the
+// record (one bit per pixel) of the pixels for the float64 re-evaluation (16 MiB + 512 B in all).  Every GPU the library runs on holds its
+// own copy at its own address until the process ends.
 // In host code this name is only a handle for hipGetSymbolAddress: kernels, memsets and copies get the
 // per-device address resolved below, never the name.
-static __device__ __align__(256) uint32_t scratch[64];
+constexpr size_t kScratchFlagsAt = 256;   // byte offsets: tickets 0, {any, count} 256, the record's words 512
+constexpr size_t kScratchBitsAt = 512;
+constexpr size_t kStaticRecordBytes = (size_t)16 << 20;  // record of the static scratch: one bit per pixel
+constexpr size_t kScratchBytes = kScratchBitsAt + kStaticRecordBytes;
+static __device__ __align__(256) uint32_t scratch[kScratchBytes / sizeof(uint32_t)];
 
 namespace {
 
@@ -172,6 +180,8 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
     const int T = d->ccm_terms;
     for (int t = 0; t < T; ++t)
       for (int ch = 0; ch < 3; ++ch) P->ccm_full[t][ch] = d->ccm[ch * T + t];
+    for (int t = 0; t < T; ++t)
+      for (int ch = 0; ch < 3; ++ch) P->ccm_lo[t][ch] = d->ccm_lo[ch * T + t];
     if (T == 3) memcpy(P->ccm3, d->ccm, sizeof(float) * 9);
     if (T > 3 && T <= 8) memcpy(P->ccm_small, d->ccm, sizeof(float) * 3 * T);
   }
@@ -191,6 +201,15 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
     P->sh_hs = (float)((double)d->sh_highlight_amount * 0.05);
     P->sh_log2f = (float)log2((double)d->sh_falloff_power);
     P->sh_chroma = (fabsf(d->sh_shadow_amount) > 50.0f || fabsf(d->sh_highlight_amount) > 50.0f) ? 1 : 0;
+    P->sh_shadow_amount = d->sh_shadow_amount;
+    P->sh_highlight_amount = d->sh_highlight_amount;
+    P->sh_falloff = d->sh_falloff_power;
+    // the largest |g(f + d) - g(f)| this stage can produce: |L' - L| <= 100 (|ss| + |hs|) |falloff - 1| (and <= 100),
+    // d = that / 116, f <= ~1; the chroma shrink moves fx, fz by up to 0.2 |fx - fy| more
+    double dl = 100.0 * (fabs((double)P->sh_ss) + fabs((double)P->sh_hs)) * fabs((double)d->sh_falloff_power - 1.0);
+    if (!(dl < 100.0)) dl = 100.0;
+    const double dm = dl / 116.0 + (P->sh_chroma ? 0.1 : 0.0);
+    P->sh_risk_bound = (float)(dm * (3.0 + 3.0 * dm + dm * dm));
   }
 
   P->usm = (d->usm_enabled && d->usm_amount > 0.0f) ? 1 : 0;
@@ -218,6 +237,8 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
     P->usm_inv_thr = P->usm_thr > 0.0f ? (float)(100.0 / (double)d->usm_threshold) : 0.0f;
     P->usm_chroma = d->usm_amount > 30.0f ? 1 : 0;
     P->usm_chroma_k = (float)((double)d->usm_amount / 100.0 * 0.1);
+    P->usm_amount = d->usm_amount;
+    P->usm_threshold = d->usm_threshold;
   }
 
   P->lab_io = d->lab_io ? 1 : 0;
@@ -348,6 +369,46 @@ int check_ctx(ss_ctx* c) {
 }
 
 
+// Where the kernels of one call keep their scratch: the unsharp-mask work-queue counters and the record of the
+// pixels for the float64 kernel.
+struct ChainScratch {
+  uint32_t* ticket;
+  RiskMap map;
+};
+
+size_t risk_record_bytes(const ChainParams& P, int batch) {
+  return risk_words_per_image(P.usm ? RISK_TILES : RISK_LINEAR, P.height, P.width) * (size_t)batch * sizeof(unsigned long long);
+}
+
+int context_scratch(ss_ctx* c, const ChainParams& P, int batch, ChainScratch* out) {
+  int rc = grow(c, &c->ws_risk, &c->ws_risk_bytes, kScratchBitsAt + risk_record_bytes(P, batch));
+  if (rc) return rc;
+  out->ticket = c->usm_ticket;
+  out->map.any = (uint32_t*)c->ws_risk;
+  out->map.count = out->map.any + 1;
+  out->map.bits = (unsigned long long*)((char*)c->ws_risk + kScratchBitsAt);
+  return SS_OK;
+}
+
+// One chain launch (pointwise or tile kernel) and, for chains with a Lab edit, the float64 kernel behind it.
+int launch_chain_and_careful(ss_ctx* c, const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
+                             const ChainScratch& S) {
+  const bool careful = chain_needs_careful(P, out_kind);
+  c->last_risk_count = careful ? S.map.count : nullptr;
+  if (careful) SS_HIP(c, hipMemsetAsync(S.map.any, 0, 256, c->stream));
+  hipError_t e = P.usm ? launch_usm(P, batch, out_kind, src, dst, S.ticket, S.map, c->stream)
+                       : launch_chain(P, batch, out_kind, src, dst, S.map, c->stream);
+  // (SS_CAREFUL=0, a debugging aid: leave the recorded pixels as the float32 kernels left them - for chains with
+  // an unsharp mask that is the stashed blur value, not a result)
+  static const bool skip = [] {
+    const char* v = getenv("SS_CAREFUL");
+    return v && v[0] == '0';
+  }();
+  if (e == hipSuccess && careful && !skip) e = launch_careful(P, batch, out_kind, src, dst, S.map, c->stream);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return SS_OK;
+}
+
 // Unsharp mask behind a colour correction of more than 3 terms: the fused tile kernel only carries the
 // 3-term matrix (larger expansions in it cost more registers than a tile kernel has), so the chain runs as
 // two launches per group of images: pointwise {negative inversion, colour correction} into a float32
@@ -362,7 +423,8 @@ size_t chain_stage_bytes() {
   return x > 0 ? (size_t)x : kChainStageBytes;
 }
 
-int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, const float* src_dev, void* dst_dev) {
+int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, const float* src_dev, void* dst_dev,
+                   const ChainScratch& S) {
   const size_t image_bytes = (size_t)P.n_px * 3 * sizeof(float);
   const size_t by_size = chain_stage_bytes() / image_bytes;
   int group = by_size > (size_t)d->batch ? d->batch : (int)by_size;
@@ -386,11 +448,11 @@ int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, cons
     B.ccm_kind = SS_CCM_NONE;
     B.ccm_terms = 0;
     if (B.gain0_dev) B.gain0_dev += first;
-    hipError_t e = launch_chain(A, n, SS_OUT_F32_LINEAR, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, c->stream);
-    if (e == hipSuccess)
-      e = launch_usm(B, n, d->out_kind, (const float*)c->ws_stage, (char*)dst_dev + (size_t)first * out_image_bytes,
-                     c->usm_ticket, c->stream);
-    if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    rc = launch_chain_and_careful(c, A, n, SS_OUT_F32_LINEAR, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, S);
+    if (rc) return rc;
+    rc = launch_chain_and_careful(c, B, n, d->out_kind, (const float*)c->ws_stage,
+                                  (char*)dst_dev + (size_t)first * out_image_bytes, S);
+    if (rc) return rc;
   }
   return SS_OK;
 }
@@ -455,6 +517,7 @@ void ss_ctx_destroy(ss_ctx* c) {
   if (c->usm_ticket) (void)hipFree(c->usm_ticket);
   if (c->ws_stage) (void)hipFree(c->ws_stage);
   if (c->ws_mask) (void)hipFree(c->ws_mask);
+  if (c->ws_risk) (void)hipFree(c->ws_risk);
   if (c->host_src) (void)hipFree(c->host_src);
   if (c->host_dst) (void)hipFree(c->host_dst);
   if (c->host_neg) (void)hipFree(c->host_neg);
@@ -501,11 +564,13 @@ int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* 
   if (rc) return rc;
   if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
     return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
-  if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3) return run_staged_usm(c, d, P, src_dev, dst_dev);
-  hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->usm_ticket, c->stream)
-                       : launch_chain(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream);
-  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-  return SS_OK;
+  ChainScratch S{c->usm_ticket, RiskMap{nullptr, nullptr, nullptr}};
+  if (chain_needs_careful(P, d->out_kind)) {
+    rc = context_scratch(c, P, d->batch, &S);
+    if (rc) return rc;
+  }
+  if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3) return run_staged_usm(c, d, P, src_dev, dst_dev, S);
+  return launch_chain_and_careful(c, P, d->batch, d->out_kind, src_dev, dst_dev, S);
 }
 
 int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev) {
@@ -530,9 +595,30 @@ int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev,
                   (long long)tiles);
   }
   if (!c->static_ticket) return fail(c, SS_ERR_HIP, "the static scratch was not resolved on device %d", c->device);
-  hipError_t e = P.usm ? launch_usm(P, d->batch, d->out_kind, src_dev, dst_dev, c->static_ticket, c->stream)
-                       : launch_chain(P, d->batch, d->out_kind, src_dev, dst_dev, c->stream);
-  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  ChainScratch S;
+  S.ticket = c->static_ticket;
+  S.map.any = (uint32_t*)((char*)c->static_ticket + kScratchFlagsAt);
+  S.map.count = S.map.any + 1;
+  S.map.bits = (unsigned long long*)((char*)c->static_ticket + kScratchBitsAt);
+  if (chain_needs_careful(P, d->out_kind) && risk_record_bytes(P, d->batch) > kStaticRecordBytes)
+    return fail(c, SS_ERR_UNSUPPORTED,
+                "a chain with a Lab edit (shadows/highlights, unsharp mask) and a float32 or 16-bit output keeps a record "
+                "of one bit per pixel for its float64 re-evaluation: %zu bytes for this call, the static scratch of "
+                "ss_chain_run_static holds %zu (about 134 million pixels): use ss_chain_run or split the batch",
+                risk_record_bytes(P, d->batch), kStaticRecordBytes);
+  return launch_chain_and_careful(c, P, d->batch, d->out_kind, src_dev, dst_dev, S);
+}
+
+int ss_chain_requeued(ss_ctx* c, uint64_t* n_pixels) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!n_pixels) return fail(c, SS_ERR_INVALID, "n_pixels is NULL");
+  *n_pixels = 0;
+  if (!c->last_risk_count) return SS_OK;
+  uint32_t n = 0;
+  SS_HIP(c, hipMemcpyAsync(&n, c->last_risk_count, sizeof n, hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  *n_pixels = n;
   return SS_OK;
 }
 

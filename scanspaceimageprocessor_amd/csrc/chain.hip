@@ -8,6 +8,7 @@
 //                  stream (nontemporal).  Algorithmic traffic: 12 B/px in + 12 / 6 / 3 B/px out; HBM-bound.
 
 #include "ss_internal.h"
+#include "ss_careful.h"
 
 namespace ss {
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ void store_one(void* dst_img, uint32_t px, const Px p
 
 template <int CCMC, bool SH, int OUT>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, const float* __restrict__ src,
-                                                    void* __restrict__ dst) {
+                                                    void* __restrict__ dst, const RiskMap Q) {
   constexpr int G = OutTraits<OUT>::G;
   constexpr int K = 4 / G;  // groups per lane per trip: 4 pixels in flight per lane
   __shared__ float4 M[ccm_needs_table<CCMC> ? SS_MAX_CCM_TERMS : 1];
@@ -83,17 +84,39 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
     // the 4 pixels of this lane go through the stages as two packed pairs (lanes past the end of the image
     // compute on zeros and store nothing)
     Px res[4];
+    bool flagged[4] = {false, false, false, false};
 #pragma unroll
     for (int q = 0; q < 4; q += 2) {
+      RiskT<v2f> risk = risk_init<OUT, v2f>();
       const Px2 o2 = finish<OUT, false, v2f>(
           front<CCMC, SH, false, v2f>(pair_px(Px{in[q].x, in[q].y, in[q].z}, Px{in[q + 1].x, in[q + 1].y, in[q + 1].z}), P,
-                                      ip, M),
+                                      ip, M, SH ? &risk : nullptr),
           P);
       res[q] = px_lo(o2);
       res[q + 1] = px_hi(o2);
+      if constexpr (SH && RiskCfg<OUT>::ENABLED) {
+        // pixels whose shadows/highlights edit float32 cannot follow (see RiskCfg): recorded for the float64 kernel
+        if (risk.flags != 0u) {  // almost never
+          const uint32_t p0 = base * G + q * 256 + threadIdx.x, p1 = p0 + 256;
+          flagged[q] = (risk.flags & 1u) && p0 < n;
+          flagged[q + 1] = (risk.flags & 2u) && p1 < n;
+        }
+      }
       // long term lists: one pair's arithmetic at a time keeps the register count down (282 -> 102 vector
       // registers for the 22-term lists, i.e. one wave per SIMD -> four)
       if constexpr (ccm_needs_table<CCMC>) __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (SH && RiskCfg<OUT>::ENABLED) {
+      // lane t holds pixels t, t + 256, ... of the chunk: a wave's k-th pixels are 64 consecutive ones, one word
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long m = __ballot(flagged[k]);
+        const uint32_t first = base * G + k * 256 + (threadIdx.x & ~63u);  // a multiple of 64
+        if ((threadIdx.x & 63u) == 0 && first < n) {
+          Q.bits[(size_t)img * ((n + 63u) / 64u) + first / 64u] = m;
+          if (m != 0ull) *Q.any = 1u;
+        }
+      }
     }
     if constexpr (G == 1) {
 #pragma unroll
@@ -133,7 +156,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
     if (px < n) {
       const F3 v = s[px];
       const ChainParams& P = params_now();
-      store_one<OUT>(d, px, finish<OUT, false, float>(front<CCMC, SH, false, float>(Px{v.x, v.y, v.z}, P, ip, M), P));
+      Px o = finish<OUT, false, float>(front<CCMC, SH, false, float>(Px{v.x, v.y, v.z}, P, ip, M), P);
+      // (the main loop has already recorded these pixels: it evaluates every pixel, it just does not store them)
+      store_one<OUT>(d, px, o);
     }
   }
 }
@@ -176,7 +201,7 @@ hipError_t launch_unpack_u16(const uint16_t* src, float* dst, uint64_t n, hipStr
 
 template <int CCMC, bool SH>
 static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                   hipStream_t st) {
+                                   const RiskMap& Q, hipStream_t st) {
   auto grid_for = [&](int G) {
     const uint32_t K = 4 / G;
     const uint64_t groups = (uint64_t)P.n_px / G;
@@ -190,19 +215,19 @@ static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind
   };
   switch (out_kind) {
     case SS_OUT_F32_LINEAR:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_LINEAR>), grid_for(1), dim3(256), 0, st, P, src, dst);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_LINEAR>), grid_for(1), dim3(256), 0, st, P, src, dst, Q);
       break;
     case SS_OUT_F32_SRGB:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_SRGB>), grid_for(1), dim3(256), 0, st, P, src, dst);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_SRGB>), grid_for(1), dim3(256), 0, st, P, src, dst, Q);
       break;
     case SS_OUT_U16_SRGB:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U16_SRGB>), grid_for(2), dim3(256), 0, st, P, src, dst);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U16_SRGB>), grid_for(2), dim3(256), 0, st, P, src, dst, Q);
       break;
     case SS_OUT_U8_SRGB:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_SRGB>), grid_for(4), dim3(256), 0, st, P, src, dst);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_SRGB>), grid_for(4), dim3(256), 0, st, P, src, dst, Q);
       break;
     case SS_OUT_U8_LINEAR:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_LINEAR>), grid_for(4), dim3(256), 0, st, P, src, dst);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_LINEAR>), grid_for(4), dim3(256), 0, st, P, src, dst, Q);
       break;
     default:
       return hipErrorInvalidValue;
@@ -212,17 +237,114 @@ static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind
 
 template <int CCMC>
 static hipError_t launch_chain_sh(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                  hipStream_t st) {
-  return P.sh ? launch_chain_out<CCMC, true>(P, batch, out_kind, src, dst, st)
-              : launch_chain_out<CCMC, false>(P, batch, out_kind, src, dst, st);
+                                  const RiskMap& Q, hipStream_t st) {
+  return P.sh ? launch_chain_out<CCMC, true>(P, batch, out_kind, src, dst, Q, st)
+              : launch_chain_out<CCMC, false>(P, batch, out_kind, src, dst, Q, st);
 }
 
-hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {
-  if (P.ccm_kind == SS_CCM_NONE) return launch_chain_sh<CCM_NONE>(P, batch, out_kind, src, dst, st);
-  if (P.ccm_terms == 3) return launch_chain_sh<CCM_LIN3>(P, batch, out_kind, src, dst, st);
-  if (P.ccm_terms <= 8) return launch_chain_sh<CCM_SMALL>(P, batch, out_kind, src, dst, st);
-  if (P.ccm_kind == SS_CCM_CHEUNG) return launch_chain_sh<CCM_CHEUNG>(P, batch, out_kind, src, dst, st);
-  return launch_chain_sh<CCM_ROOT>(P, batch, out_kind, src, dst, st);
+hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, const RiskMap& Q,
+                        hipStream_t st) {
+  if (P.ccm_kind == SS_CCM_NONE) return launch_chain_sh<CCM_NONE>(P, batch, out_kind, src, dst, Q, st);
+  if (P.ccm_terms == 3) return launch_chain_sh<CCM_LIN3>(P, batch, out_kind, src, dst, Q, st);
+  if (P.ccm_terms <= 8) return launch_chain_sh<CCM_SMALL>(P, batch, out_kind, src, dst, Q, st);
+  if (P.ccm_kind == SS_CCM_CHEUNG) return launch_chain_sh<CCM_CHEUNG>(P, batch, out_kind, src, dst, Q, st);
+  return launch_chain_sh<CCM_ROOT>(P, batch, out_kind, src, dst, Q, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// float64 re-evaluation of the queued pixels (ss_careful.h)
+// ------------------------------------------------------------------------------------------------
+
+// One workgroup takes 256 words of the record at a time, counts their bits, and deals the recorded pixels out
+// evenly over its threads (prefix sums in LDS), so a word with many recorded pixels does not hold a wave up.
+__global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, const RiskMap Q, int layout, int batch,
+                                                      const float* __restrict__ src, void* __restrict__ dst, int out_kind) {
+  if (*Q.any == 0u) return;
+  const ChainParams* Pk = (const ChainParams*)__builtin_amdgcn_kernarg_segment_ptr();  // P is the first argument
+  const bool enc = out_kind != SS_OUT_F32_LINEAR && out_kind != SS_OUT_U8_LINEAR;
+  const int W = P.width, H = P.height;
+  const uint32_t tiles_x = (uint32_t)(W + kRiskTileWidth - 1) / kRiskTileWidth;
+  const size_t wpi = risk_words_per_image(layout, H, W);
+  const size_t n_words = wpi * (size_t)batch;
+  __shared__ unsigned long long words[256];
+  __shared__ uint32_t start[257];
+  for (size_t chunk = (size_t)blockIdx.x * 256; chunk < n_words; chunk += (size_t)gridDim.x * 256) {
+    const size_t g = chunk + threadIdx.x;
+    const unsigned long long w = g < n_words ? Q.bits[g] : 0ull;
+    if (__syncthreads_or(w != 0ull) == 0) continue;
+    words[threadIdx.x] = w;
+    // inclusive scan of the bit counts
+    uint32_t v = (uint32_t)__popcll(w);
+    start[threadIdx.x + 1] = v;
+    if (threadIdx.x == 0) start[0] = 0;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint32_t add = threadIdx.x + 1 > (uint32_t)d ? start[threadIdx.x + 1 - d] : 0u;
+      __syncthreads();
+      start[threadIdx.x + 1] += add;
+      __syncthreads();
+    }
+    const uint32_t total = start[256];
+    if (threadIdx.x == 0) atomicAdd(Q.count, total);
+    for (uint32_t i = threadIdx.x; i < total; i += 256) {
+      // the word that holds the i-th recorded pixel of the chunk: start[j] <= i < start[j + 1]
+      uint32_t lo = 0, hi = 256;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (start[mid] <= i) lo = mid; else hi = mid;
+      }
+      unsigned long long ww = words[lo];
+      for (uint32_t k = i - start[lo]; k > 0; --k) ww &= ww - 1ull;  // drop the k lowest set bits
+      const uint32_t bit = (uint32_t)__ffsll((long long)ww) - 1u;
+      const size_t gw = chunk + lo;
+      const uint32_t img = (uint32_t)(gw / wpi);
+      const size_t wi = gw - (size_t)img * wpi;
+      uint32_t px;
+      if (layout == RISK_LINEAR) {
+        px = (uint32_t)wi * 64u + bit;
+      } else {
+        const uint32_t y = (uint32_t)(wi / (tiles_x * 2u)), r2 = (uint32_t)(wi - (size_t)y * tiles_x * 2u);
+        px = y * (uint32_t)W + (r2 >> 1) * (uint32_t)kRiskTileWidth + 2u * bit + (r2 & 1u);
+      }
+      const size_t at = (size_t)img * (size_t)P.n_px + px;
+      const float* sp = src + at * 3;
+      float Lb = 0.0f;
+      if (P.usm) {  // left by the tile kernel in the pixel's output slot
+        if (out_kind == SS_OUT_U16_SRGB) {
+          const uint16_t* d = reinterpret_cast<const uint16_t*>(dst) + at * 3;
+          Lb = __uint_as_float((uint32_t)d[0] | ((uint32_t)d[1] << 16));
+        } else {
+          Lb = reinterpret_cast<const float*>(dst)[at * 3];
+        }
+      }
+      double v3[3];
+      careful_pixel(Pk, (int)img, sp[0], sp[1], sp[2], Lb, enc, v3);
+      if (out_kind == SS_OUT_U16_SRGB) {
+        uint16_t* d = reinterpret_cast<uint16_t*>(dst) + at * 3;
+        for (int c = 0; c < 3; ++c) d[c] = (uint16_t)fmin(fmax(v3[c] * 65535.0, 0.0), 65535.0);
+      } else {
+        float* d = reinterpret_cast<float*>(dst) + at * 3;
+        d[0] = (float)v3[0], d[1] = (float)v3[1], d[2] = (float)v3[2];
+      }
+    }
+    __syncthreads();  // the next chunk overwrites words[] and start[]
+  }
+}
+
+hipError_t launch_careful(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, const RiskMap& Q,
+                          hipStream_t st) {
+  const int layout = P.usm ? RISK_TILES : RISK_LINEAR;
+  const size_t n_words = risk_words_per_image(layout, P.height, P.width) * (size_t)batch;
+  size_t blocks = (n_words + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(careful_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, Q, layout, batch, src, dst, out_kind);
+  return hipGetLastError();
+}
+
+bool chain_needs_careful(const ChainParams& P, int out_kind) {
+  // (chains on Lab data never record a pixel, but their kernels write the - empty - record all the same)
+  if (!(P.sh || P.usm)) return false;
+  return out_kind == SS_OUT_F32_LINEAR || out_kind == SS_OUT_F32_SRGB || out_kind == SS_OUT_U16_SRGB;
 }
 
 }  // namespace ss

@@ -1,0 +1,226 @@
+// Float64 evaluation of the correction chain for single pixels.
+//
+// The reference computes the chain in float64 (colour-science converts its input with as_float_array).  The
+// float32 kernels follow it to a few 1e-7, which every output encoding tolerates except in one situation: a Lab
+// edit (shadows/highlights, unsharp mask) that pushes one channel of a saturated pixel to almost zero.  The edited
+// pixel is linear + M_inv (g(f + d) - g(f)) with terms of size ~1 that cancel to ~1e-4; float32 keeps that sum to
+// ~3e-7 absolute, and the two sRGB encodes that follow have slope 12.92 each near zero: 167 x 3e-7 = 3 steps of 16
+// bits.  Such pixels are rare and easy to recognise (RiskCfg in ss_device.h): the float32 kernels queue them and a
+// second kernel evaluates them again here, from the source pixel, operation for operation as the reference does,
+// in float64.  Only the blurred lightness is taken over from the float32 pipeline (the reference blurs in
+// float32 too).  A few thousand instructions per pixel, paid per queued pixel only.
+#pragma once
+
+#include "ss_device.h"
+
+namespace ss {
+
+namespace careful {
+
+__device__ __forceinline__ double clip01(double x) { return fmin(fmax(x, 0.0), 1.0); }
+__device__ __forceinline__ double spow(double a, double p) {
+  if (a == 0.0) return 0.0;
+  const double m = pow(fabs(a), p);
+  return a < 0.0 ? -m : m;
+}
+__device__ __forceinline__ double encode(double L) { return L <= 0.0031308 ? L * 12.92 : 1.055 * spow(L, 1.0 / 2.4) - 0.055; }
+__device__ __forceinline__ double decode(double V) {
+  return V <= 12.92 * 0.0031308 ? V / 12.92 : spow((V + 0.055) / 1.055, 2.4);
+}
+__device__ __forceinline__ double lab_f(double t) {
+  const double T = 24.0 / 116.0;
+  return t > T * T * T ? spow(t, 1.0 / 3.0) : (841.0 / 108.0) * t + 16.0 / 116.0;
+}
+__device__ __forceinline__ double lab_finv(double f) {
+  return f > 24.0 / 116.0 ? f * f * f : (f - 16.0 / 116.0) * (108.0 / 841.0);
+}
+
+struct Lab3 {
+  double L, a, b;
+};
+
+// colour.sRGB_to_XYZ (decode first) and colour.XYZ_to_Lab under D65
+__device__ __forceinline__ Lab3 rgb_to_lab(const double rgb[3]) {
+  const double m[9] = {0.4124, 0.3576, 0.1805, 0.2126, 0.7152, 0.0722, 0.0193, 0.1192, 0.9505};
+  const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
+  const double r = decode(rgb[0]), g = decode(rgb[1]), b = decode(rgb[2]);
+  double f[3];
+  for (int k = 0; k < 3; ++k) f[k] = lab_f((m[3 * k] * r + m[3 * k + 1] * g + m[3 * k + 2] * b) / white[k]);
+  return Lab3{116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])};
+}
+
+// colour.Lab_to_XYZ, colour.XYZ_to_sRGB (the IEC matrix as published, sRGB encode), clip
+__device__ __forceinline__ void lab_to_rgb(const Lab3 q, double rgb[3]) {
+  const double inv[9] = {3.2406, -1.5372, -0.4986, -0.9689, 1.8758, 0.0415, 0.0557, -0.2040, 1.0570};
+  const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
+  const double fy = (q.L + 16.0) / 116.0, fx = q.a / 500.0 + fy, fz = fy - q.b / 200.0;
+  const double x = lab_finv(fx) * white[0], y = lab_finv(fy) * white[1], z = lab_finv(fz) * white[2];
+  for (int k = 0; k < 3; ++k) rgb[k] = clip01(encode(inv[3 * k] * x + inv[3 * k + 1] * y + inv[3 * k + 2] * z));
+}
+
+// term lists of colour.characterisation: matrix_augmented_Cheung2004 / polynomial_expansion_Finlayson2015 (roots)
+__device__ inline int expand(int kind, int terms, double R, double G, double B, double e[SS_MAX_CCM_TERMS]) {
+  int n = 0;
+  e[n++] = R;
+  e[n++] = G;
+  e[n++] = B;
+  if (terms == 3) return n;
+  if (kind == SS_CCM_CHEUNG) {
+    if (terms == 5) {
+      e[n++] = R * G * B;
+      e[n++] = 1.0;
+      return n;
+    }
+    e[n++] = R * G;
+    e[n++] = R * B;
+    e[n++] = G * B;
+    if (terms == 7) {
+      e[n++] = 1.0;
+      return n;
+    }
+    if (terms == 8) {
+      e[n++] = R * G * B;
+      e[n++] = 1.0;
+      return n;
+    }
+    e[n++] = R * R;
+    e[n++] = G * G;
+    e[n++] = B * B;
+    if (terms == 10) {
+      e[n++] = 1.0;
+      return n;
+    }
+    e[n++] = R * G * B;
+    if (terms == 11) {
+      e[n++] = 1.0;
+      return n;
+    }
+    if (terms == 14) {
+      e[n++] = R * R * R;
+      e[n++] = G * G * G;
+      e[n++] = B * B * B;
+      e[n++] = 1.0;
+      return n;
+    }
+    e[n++] = R * R * G;
+    e[n++] = G * G * B;
+    e[n++] = B * B * R;
+    if (terms >= 19) {
+      e[n++] = R * R * B;
+      e[n++] = G * G * R;
+      e[n++] = B * B * G;
+    }
+    e[n++] = R * R * R;
+    e[n++] = G * G * G;
+    e[n++] = B * B * B;
+    if (terms == 17 || terms == 20) e[n++] = 1.0;
+    if (terms == 22) {
+      e[n++] = R * R * G * B;
+      e[n++] = R * G * G * B;
+      e[n++] = R * G * B * B;
+    }
+    return n;
+  }
+  e[n++] = spow(R * G, 0.5);
+  e[n++] = spow(G * B, 0.5);
+  e[n++] = spow(R * B, 0.5);
+  if (terms == 6) return n;
+  const double third = 1.0 / 3.0;
+  e[n++] = spow(R * G * G, third);
+  e[n++] = spow(G * B * B, third);
+  e[n++] = spow(R * B * B, third);
+  e[n++] = spow(G * R * R, third);
+  e[n++] = spow(B * G * G, third);
+  e[n++] = spow(B * R * R, third);
+  e[n++] = spow(R * G * B, third);
+  if (terms == 13) return n;
+  e[n++] = spow(R * R * R * G, 0.25);
+  e[n++] = spow(R * R * R * B, 0.25);
+  e[n++] = spow(G * G * G * R, 0.25);
+  e[n++] = spow(G * G * G * B, 0.25);
+  e[n++] = spow(B * B * B * R, 0.25);
+  e[n++] = spow(B * B * B * G, 0.25);
+  e[n++] = spow(R * R * G * B, 0.25);
+  e[n++] = spow(G * G * R * B, 0.25);
+  e[n++] = spow(B * B * R * G, 0.25);
+  return n;
+}
+
+}  // namespace careful
+
+// The whole chain for the pixel (sr, sg, sb) of image `img`, stages 1-7, in float64.  `Lb`: the blurred
+// lightness at the pixel (used when the chain has an unsharp mask).  `encode_out`: stage 7 applies the sRGB
+// encoding (every output kind except the two linear ones).  out[3]: the values the quantiser or the float store
+// receives.  P points at the kernel's parameter block in memory (its kernel-argument segment).
+__device__ inline void careful_pixel(const ChainParams* P, int img, float sr, float sg,
+                                                               float sb, float Lb, bool encode_out, double out[3]) {
+  using namespace careful;
+  double p[3];
+  {
+    // stage 1: the reference inverts in float32 (invert_negative_auto works on a float32 array)
+    float x[3] = {sr, sg, sb};
+    if (P->neg) {
+      for (int c = 0; c < 3; ++c) {
+        const float lo = P->neg_dev ? P->neg_dev[img * SS_NEG_PARAM_STRIDE + c] : P->neg_lo[c];
+        const float inv = P->neg_dev ? P->neg_dev[img * SS_NEG_PARAM_STRIDE + 3 + c] : P->neg_inv[c];
+        x[c] = 1.0f - clamp01((clamp01(x[c]) - lo) * inv);
+      }
+    }
+    for (int c = 0; c < 3; ++c) p[c] = (double)x[c];
+  }
+  if (P->ccm_kind != SS_CCM_NONE) {  // stage 2
+    double e[SS_MAX_CCM_TERMS];
+    const int n = expand(P->ccm_kind, P->ccm_terms, p[0], p[1], p[2], e);
+    double o[3] = {0.0, 0.0, 0.0};
+    for (int t = 0; t < n; ++t)
+      for (int c = 0; c < 3; ++c) o[c] += ((double)P->ccm_full[t][c] + (double)P->ccm_lo[t][c]) * e[t];
+    for (int c = 0; c < 3; ++c) p[c] = o[c];
+  }
+  for (int s = 0; s < P->n_gain; ++s) {  // stage 3
+    const double g0 = (s == 0 && P->gain0_dev) ? (double)P->gain0_dev[img] : 1.0;
+    for (int c = 0; c < 3; ++c) p[c] = clip01(p[c] * (g0 * (double)P->gain[s][c]));
+  }
+  if (P->sh) {  // stage 4 (editingTools.py:508-541)
+    Lab3 q = rgb_to_lab(p);
+    const double Ln = q.L / 100.0;
+    const double ss = (double)P->sh_shadow_amount * 0.05, hs = (double)P->sh_highlight_amount * 0.05;
+    const double falloff = (double)P->sh_falloff;
+    const double h_adj = hs != 0.0 ? hs * (pow(falloff, Ln) - 1.0) : 0.0;
+    const double s_adj = ss != 0.0 ? ss * (pow(falloff, 1.0 - Ln) - 1.0) : 0.0;
+    const double total = (h_adj + s_adj) * 100.0;
+    q.L = fmin(fmax(q.L + total, 0.0), 100.0);
+    if (P->sh_chroma) {
+      const double cs = 1.0 - fmin(fmax(fabs(total) / 20.0 * 0.05, 0.0), 0.2);
+      q.a *= cs;
+      q.b *= cs;
+    }
+    lab_to_rgb(q, p);
+  }
+  if (P->usm) {  // stage 5 (editingTools.py:745-817)
+    Lab3 q = rgb_to_lab(p);
+    const double Ln = q.L / 100.0;
+    const double amount = (double)P->usm_amount;
+    const double thr = (double)P->usm_threshold / 100.0;
+    double um = Ln - (double)Lb;
+    if (thr > 0.0) {
+      const double es = fabs(um);
+      um *= es > thr ? 1.0 : es / thr;
+    }
+    const double hm = Ln > 0.9 ? 1.0 - (Ln - 0.9) * 10.0 : 1.0;
+    const double sm = Ln < 0.1 ? Ln * 10.0 : 1.0;
+    const double ad = fmin(fmax(hm * sm, 0.1), 1.0);
+    q.L = clip01(Ln + um * (amount / 50.0) * ad) * 100.0;
+    if (amount > 30.0) {
+      const double boost = 1.0 + fabs(um) * (amount / 100.0) * 0.1;
+      q.a = fmin(fmax(q.a * boost, -127.0), 127.0);
+      q.b = fmin(fmax(q.b * boost, -127.0), 127.0);
+    }
+    lab_to_rgb(q, p);
+  }
+  for (int c = 0; c < 3; ++c) {  // stages 6-7
+    double v = P->final_clip ? clip01(p[c]) : p[c];
+    out[c] = encode_out ? encode(v) : v;
+  }
+}
+
+}  // namespace ss

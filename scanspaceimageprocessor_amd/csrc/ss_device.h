@@ -49,6 +49,14 @@ struct ChainParams {
   // Full 3 x T table for T > 3, as [t] = {row R, row G, row B, 0}.  Kept LAST and only ever read with a
   // runtime index (staged into LDS at kernel start) so that it never occupies scalar registers.
   float ccm_full[SS_MAX_CCM_TERMS][4];
+
+  // Read by the float64 evaluation of single pixels only (ss_careful.h), through a pointer to the kernel-argument
+  // segment: the stage arguments as the caller gave them, the low-order parts of the colour-correction
+  // coefficients (ccm_full + ccm_lo = the float64 coefficient), and the largest B (see lab_edit_at_risk) the
+  // shadows/highlights stage of this chain can produce.
+  float sh_shadow_amount, sh_highlight_amount, sh_falloff, usm_amount, usm_threshold;
+  float sh_risk_bound;
+  float ccm_lo[SS_MAX_CCM_TERMS][4];
 };
 
 // sRGB <-> XYZ of colour-science's sRGB colourspace: IEC 61966-2-1:1999 gives both matrices to four decimals
@@ -240,6 +248,108 @@ __device__ __forceinline__ LabFT<V> linear_to_labf(const PxT<V> lin, const Chain
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ v2f vmin(v2f a, v2f b) { return v2f{fminf(a.x, b.x), fminf(a.y, b.y)}; }
 
+__device__ __forceinline__ float vmin3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ v2f vmin3(v2f a, v2f b, v2f c) { return v2f{vmin3(a.x, b.x, c.x), vmin3(a.y, b.y, c.y)}; }
+__device__ __forceinline__ float vmax3abs(float a, float b, float c) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)); }
+__device__ __forceinline__ v2f vmax3abs(v2f a, v2f b, v2f c) {
+  return v2f{vmax3abs(a.x, b.x, c.x), vmax3abs(a.y, b.y, c.y)};
+}
+
+// ---- which Lab edits float32 cannot follow ---------------------------------------------------------
+// The edited pixel is linear + M_inv (g(f + d) - g(f)): terms of a size up to B = 3.3 mx, mx = max |g(f + d) - g(f)|
+// over X, Y, Z (3.3 ~ the largest row sum of |M_inv|), that can cancel to a channel value o near zero.  float32
+// keeps the sum to ~3e-7 B absolute; the sRGB encodes that follow multiply that by their slopes: the edit's own
+// encode (12.92 below 0.0031, ~0.44 o^-0.58 above) and, for encoded outputs, the output encode on top (together
+// min(167, ~0.14 / o)).  Held against a third of the output's tolerance (1e-5 on float data, one step on 16 bits)
+// this says a pixel is at risk when mx > MIN_MX and one of its edited channels lies in (-4e-6, mx / RATIO).
+// Such pixels are recorded and evaluated again in float64 by a second kernel (ss_careful.h).  8-bit outputs never
+// need it.
+template <int OUT>
+struct RiskCfg {
+  static constexpr bool ENCODED = OUT == SS_OUT_F32_SRGB || OUT == SS_OUT_U16_SRGB;
+  static constexpr bool ENABLED = OUT == SS_OUT_F32_LINEAR || ENCODED;
+  static constexpr float MIN_MX = ENCODED ? 0.05f / 3.3f : 1.29f / 3.3f;
+  static constexpr float RATIO = ENCODED ? 60.0f / 3.3f : 250.0f / 3.3f;
+};
+constexpr float kRiskBelowZero = -4.0e-6f;
+
+// What an edit reports: on entry `mx` holds what an earlier edit of the same pixel contributed, on return the
+// total; `flags` (bit 0: the pixel, or the first of a pair; bit 1: the second) says which pixels are at risk.  The
+// flags are only worked out when `min_mx` is finite (the caller's output needs them), and then only by waves that
+// hold a pixel with mx > min_mx at all: almost none.
+template <class V>
+struct RiskT {
+  V mx;
+  float min_mx, inv_ratio;
+  uint32_t flags;
+};
+template <int OUT, class V>
+__device__ __forceinline__ RiskT<V> risk_init(V carried = (V)(0.0f)) {
+  return RiskT<V>{carried, RiskCfg<OUT>::ENABLED ? RiskCfg<OUT>::MIN_MX : __builtin_inff(), 1.0f / RiskCfg<OUT>::RATIO, 0u};
+}
+// only the size of the edit is wanted (it is handed to a later stage)
+template <class V>
+__device__ __forceinline__ RiskT<V> risk_size_only() {
+  return RiskT<V>{(V)(0.0f), __builtin_inff(), 0.0f, 0u};
+}
+__device__ __forceinline__ bool risk_channel(float o, float lim) { return o > kRiskBelowZero && o < lim; }
+__device__ __forceinline__ void risk_eval(RiskT<float>& k, float r, float g, float b) {
+  if (!(k.min_mx < __builtin_inff())) return;
+  const bool big = k.mx > k.min_mx;
+  if (__ballot(big) != 0ull) {
+    const float lim = k.mx * k.inv_ratio;
+    if (big && (risk_channel(r, lim) || risk_channel(g, lim) || risk_channel(b, lim))) k.flags = 1u;
+  }
+}
+__device__ __forceinline__ void risk_eval(RiskT<v2f>& k, v2f r, v2f g, v2f b) {
+  if (!(k.min_mx < __builtin_inff())) return;
+  const bool big0 = k.mx.x > k.min_mx, big1 = k.mx.y > k.min_mx;
+  if (__ballot(big0 || big1) != 0ull) {
+    const float lim0 = k.mx.x * k.inv_ratio, lim1 = k.mx.y * k.inv_ratio;
+    if (big0 && (risk_channel(r.x, lim0) || risk_channel(g.x, lim0) || risk_channel(b.x, lim0))) k.flags |= 1u;
+    if (big1 && (risk_channel(r.y, lim1) || risk_channel(g.y, lim1) || risk_channel(b.y, lim1))) k.flags |= 2u;
+  }
+}
+
+// A shadows/highlights edit in front of the unsharp mask hands its mx to the sharpen stage, which sees the pixel
+// only after the edit, as a 3-bit level in the signs of the three channel values (the edit returns them clipped to
+// [0, 1], so the signs are free): level 0 = below 2^-6 (nothing to carry), level L = [2^(L-7), 2^(L-6)), carried as
+// its upper edge, level 7 = 1 or more, carried as the largest value the stage's settings allow.
+__device__ __forceinline__ uint32_t risk_level(float mx) {
+  const int e = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;  // floor(log2 mx)
+  const int l = e + 7;
+  return (uint32_t)(l < 0 ? 0 : (l > 7 ? 7 : l));
+}
+__device__ __forceinline__ float risk_tag(float v, uint32_t level, int bit) {
+  return __uint_as_float(__float_as_uint(v) | (((level >> bit) & 1u) << 31));
+}
+__device__ __forceinline__ float risk_carried(float c0, float c1, float c2, float bound_max) {
+  const uint32_t l = (__float_as_uint(c0) >> 31) | ((__float_as_uint(c1) >> 31) << 1) | ((__float_as_uint(c2) >> 31) << 2);
+  if (l == 0) return 0.0f;
+  return l == 7 ? bound_max : __uint_as_float((l + 121u) << 23);  // 2^(l - 6)
+}
+
+// Record of the pixels to evaluate again: one bit per pixel, written by the float32 kernels as whole 64-bit words
+// (a wave's ballot), every word of the record on every launch, so it needs no clearing and holds any number of
+// pixels.  Two layouts, after how the kernels walk an image:
+//   RISK_LINEAR  (pointwise kernel)  word w of an image = pixels [64 w, 64 w + 64), bit b = pixel 64 w + b;
+//   RISK_TILES   (tile kernel)       words (y * tiles_x + t) * 2 + e, e = 0 / 1, of an image = row y of tile column t:
+//                                    bit b of word e = pixel x = 128 t + 2 b + e.
+// `any` is raised (to 1) by every wave that records a pixel; the launcher clears it, the float64 kernel returns at
+// once when it is still 0.  For chains with an unsharp mask the blurred lightness of a recorded pixel waits in the
+// pixel's own output slot (its first 4 bytes), which the float64 kernel overwrites with the result.
+enum RiskLayout { RISK_LINEAR = 0, RISK_TILES = 1 };
+struct RiskMap {
+  unsigned long long* bits;
+  uint32_t* any;
+  uint32_t* count;  // total of recorded pixels, added up by the float64 kernel (statistics)
+};
+constexpr int kRiskTileWidth = 128;
+__host__ __device__ inline size_t risk_words_per_image(int layout, int height, int width) {
+  return layout == RISK_LINEAR ? ((size_t)height * width + 63) / 64
+                               : (size_t)height * ((width + kRiskTileWidth - 1) / kRiskTileWidth) * 2;
+}
+
 // g(f + d) - g(f) on the cubic segment of g: d (3 f (f + d) + d^2), free of cancellation
 template <class V>
 __device__ __forceinline__ V finv_delta_cubic(V f, V d) {
@@ -262,7 +372,7 @@ __device__ __forceinline__ V finv_delta_any(V f, V d) {
 // linear + M_inv * (g(f + df) - g(f)): the edited pixel before _lab_to_rgb encodes and clips it
 template <class V>
 __device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy,
-                                                 const V dfz) {
+                                                 const V dfz, RiskT<V>* risk = nullptr) {
   // (a wave-uniform shortcut for "every pixel on the cubic segment" costs as much to decide as it saves)
   const V dx = finv_delta_any(f.fx, dfx), dy = finv_delta_any(f.fy, dfy), dz = finv_delta_any(f.fz, dfz);
   // the unedited part of the round trip: (I + E) . linear, E = the mismatch of the two IEC matrices
@@ -273,14 +383,18 @@ __device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V
   o.r = mad<V>(kLab.inv[0], dx, mad<V>(kLab.inv[1], dy, mad<V>(kLab.inv[2], dz, ur)));
   o.g = mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, ug)));
   o.b = mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, ub)));
+  if (risk) {
+    risk->mx = risk->mx + vmax3abs(dx, dy, dz);
+    risk_eval(*risk, o.r, o.g, o.b);
+  }
   return o;
 }
 
 // clip(encode(.)) of it: what _lab_to_rgb returns for the edited pixel
 template <class V>
 __device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy, const V dfz,
-                                              const ChainParams& P) {
-  const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz);
+                                              const ChainParams& P, RiskT<V>* risk = nullptr) {
+  const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz, risk);
   return PxT<V>{clamp01(srgb_encode(o.r)), clamp01(srgb_encode(o.g)), clamp01(srgb_encode(o.b))};
 }
 
@@ -536,7 +650,7 @@ __device__ __forceinline__ LabT<V> sh_on_lab(LabT<V> q, const ChainParams& P) {
 // clip(x, 0, 1) (encode is increasing and fixes 0 and 1), so a consumer that would decode the pixel again
 // - the next Lab edit - gets it without the encode/decode pair and without that pair's rounding.
 template <bool DECODED = false, class V>
-__device__ __forceinline__ PxT<V> sh_on_rgb(const PxT<V> p, const ChainParams& P) {
+__device__ __forceinline__ PxT<V> sh_on_rgb(const PxT<V> p, const ChainParams& P, RiskT<V>* risk = nullptr) {
   const PxT<V> lin{srgb_decode(p.r), srgb_decode(p.g), srgb_decode(p.b)};
   const LabFT<V> f = linear_to_labf(lin, P);
   const V L = mad<V>(f.fy, 116.0f, -16.0f);
@@ -550,10 +664,10 @@ __device__ __forceinline__ PxT<V> sh_on_rgb(const PxT<V> p, const ChainParams& P
     dfz = dfy + (f.fy - f.fz) * shrink;
   }
   if constexpr (DECODED) {
-    const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz);
+    const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz, risk);
     return PxT<V>{clamp01(o.r), clamp01(o.g), clamp01(o.b)};
   } else {
-    return shifted_rgb(lin, f, dfx, dfy, dfz, P);
+    return shifted_rgb(lin, f, dfx, dfy, dfz, P, risk);
   }
 }
 
@@ -563,7 +677,7 @@ __device__ __forceinline__ PxT<V> sh_on_rgb(const PxT<V> p, const ChainParams& P
 // RGB data.  Everything else about a chain is then dead code and its parameters never reach registers.
 template <int CCMC, bool SH, bool PLAIN = false, class V = float>
 __device__ __forceinline__ PxT<V> front(PxT<V> p, const ChainParams& P, const ImgParams& ip,
-                                        const float4* __restrict__ M) {
+                                        const float4* __restrict__ M, RiskT<V>* risk = nullptr) {
   if constexpr (PLAIN) {
     if constexpr (CCMC == CCM_LIN3) {
       // clip(gain * (M p)) as clip((gain M) p): three instructions per pixel fewer, same value to an ulp
@@ -607,7 +721,7 @@ __device__ __forceinline__ PxT<V> front(PxT<V> p, const ChainParams& P, const Im
         const LabT<V> q = sh_on_lab(LabT<V>{p.r, p.g, p.b}, P);
         p = PxT<V>{q.L, q.a, q.b};
       } else {
-        p = sh_on_rgb<false, V>(p, P);
+        p = sh_on_rgb<false, V>(p, P, risk);
       }
     }
   }
@@ -618,7 +732,7 @@ __device__ __forceinline__ PxT<V> front(PxT<V> p, const ChainParams& P, const Im
 // (L, a, b) unchanged for Lab data.
 template <int CCMC, bool PLAIN = false, class V = float>
 __device__ __forceinline__ PxT<V> front_decoded(PxT<V> p, const ChainParams& P, const ImgParams& ip,
-                                                const float4* __restrict__ M) {
+                                                const float4* __restrict__ M, RiskT<V>* risk = nullptr) {
   p = front<CCMC, false, PLAIN, V>(p, P, ip, M);
   if constexpr (!PLAIN) {
     if (P.lab_io) {
@@ -628,7 +742,7 @@ __device__ __forceinline__ PxT<V> front_decoded(PxT<V> p, const ChainParams& P, 
       }
       return p;
     }
-    if (P.sh) return sh_on_rgb<true, V>(p, P);
+    if (P.sh) return sh_on_rgb<true, V>(p, P, risk);
   }
   return PxT<V>{srgb_decode(p.r), srgb_decode(p.g), srgb_decode(p.b)};
 }
@@ -661,7 +775,8 @@ __device__ __forceinline__ LabT<V> usm_on_lab(const V Ln, const V a, const V b, 
 // The same edit on RGB data: `lin` = decoded (linear) pixel, Ln = L/100 of it, Lb = blurred Ln.
 // Returns what _lab_to_rgb gives for the sharpened pixel (sRGB-encoded, clipped).
 template <bool PLAIN = false, class V = float>
-__device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const V Lb, const ChainParams& P) {
+__device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const V Lb, const ChainParams& P,
+                                             RiskT<V>* risk = nullptr) {
   LabFT<V> f;
   f.fy = mad<V>(Ln, 100.0f / 116.0f, 16.0f / 116.0f);
   f.fx = lab_f(mad<V>(kLab.fwd[0], lin.r, mad<V>(kLab.fwd[1], lin.g, lin.b * kLab.fwd[2])));
@@ -684,7 +799,7 @@ __device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const
     dfx = mad<V>(clampf(a * boost, -127.0f, 127.0f) - a, 1.0f / 500.0f, dfy);
     dfz = mad<V>(clampf(b * boost, -127.0f, 127.0f) - b, -1.0f / 200.0f, dfy);
   }
-  return shifted_rgb(lin, f, dfx, dfy, dfz, P);
+  return shifted_rgb(lin, f, dfx, dfy, dfz, P, risk);
 }
 
 // ---- stages 6-7: final clip, encoding, quantisation -------------------------------------------

@@ -301,11 +301,11 @@ def test_sharpen_of_random_shapes_and_work_queues(swatches, monkeypatch, seed):
         x = lv.colour_correction(imgs[i], M_T, M_R) if with_ccm else imgs[i].astype(np.float64)
         c = np.clip(oc.adjust_sharpen(np.clip(x * 1.1, 0, 1), amount, radius, threshold), 0, 1)
         if out == "f32":
-            assert np.max(np.abs(got[i] - c)) <= F32_TOL, (seed, h, w, b, radius)
+            assert np.all(np.abs(got[i] - c) <= F32_TOL + _blur_allowance(c, amount, False)), (seed, h, w, b, radius)
         else:
             want = np.clip(lv.eotf_inverse_sRGB(c) * 65535.0, 0, 65535.0).astype(np.uint16)
             diff = np.abs(got[i].astype(np.int64) - want.astype(np.int64))
-            extra = _lab_edit_allowance(want / 65535.0, 1, True) * 65535.0
+            extra = _blur_allowance(want / 65535.0, amount, True) * 65535.0
             assert np.all(diff <= 1 + np.floor(F32_TOL * 65535.0 + extra)), (seed, h, w, b, radius, int(diff.max()))
 
 
@@ -379,7 +379,7 @@ def test_usm_behind_larger_colour_corrections(swatches, monkeypatch, stage_bytes
         pos = oc.invert_negative_auto(imgs[i], 0.05, 0.995, legacy=True) if negative else imgs[i]
         c = np.clip(lv.colour_correction(pos, M_T, M_R, method=method, **kw) * float(factors[i]), 0, 1)
         want = np.clip(oc.adjust_sharpen(c, 60.0, 2.0, 0.0), 0, 1)
-        assert np.max(np.abs(got[i] - want)) <= 3 * F32_TOL
+        assert np.max(np.abs(got[i] - want)) <= F32_TOL
 
 
 @pytest.mark.parametrize("radius", [1.0, 2.0])
@@ -574,13 +574,14 @@ def fuzz_case(seed, M_T, M_R):
               {"method": "Finlayson 2015", "degree": 3}][int(rng.integers(0, 7))]
     if ccm_kw is not None and ccm_kw.get("method") == "Finlayson 2015":
         neg = None  # the roots have unbounded slope at the zeros an inversion clips to: float32 cannot follow float64 there
-    gains = [rng.uniform(0.6, 1.6, 3) if rng.random() < 0.5 else float(rng.uniform(0.6, 1.6))
-             for _ in range(int(rng.integers(0, 4)))]
+    gains = [rng.uniform(0.6, 1.6, 3).astype(np.float32).astype(np.float64) if rng.random() < 0.5
+             else float(np.float32(rng.uniform(0.6, 1.6))) for _ in range(int(rng.integers(0, 4)))]
     sh = usm = None
     if rng.random() < 0.5:
         # the GUI's range (amounts far above it saturate everything; the chroma branch they switch on is pinned by
         # the reference vectors)
-        sh = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), 7.0)
+        # (values a float32 holds exactly: the C ABI takes the amounts as floats)
+        sh = (float(np.float32(rng.uniform(-1, 1))), float(np.float32(rng.uniform(-1, 1))), 7.0)
     if rng.random() < 0.6:
         usm = (float(rng.choice([0.5, 20.0, 45.0, 80.0])), float(rng.choice([0.5, 1.0, 2.0, 2.5])),
                float(rng.choice([0.0, 2.0])))
@@ -607,7 +608,7 @@ def fuzz_case(seed, M_T, M_R):
     return imgs, kw, (neg, ccm_kw, gains, sh, usm, final_clip, out)
 
 
-LAB_EDIT_ERR = 3.0e-7  # float32 evaluation error of one Lab edit, absolute, in the linear light it returns
+BLUR_LAST_BITS = 1.5e-7  # what the float32 blurred lightness of two float32 blurs may differ by (about 2 ulp at 0.5)
 
 
 def _encode_slope(x):
@@ -616,21 +617,22 @@ def _encode_slope(x):
     return np.where(x <= 0.0031308, 12.92, (1.055 / 2.4) * x ** (1.0 / 2.4 - 1.0))
 
 
-def _lab_edit_allowance(v, n_edits, output_encoded):
-    """What the float32 evaluation of `n_edits` Lab edits may add to the error of the final value `v`.
+def _blur_allowance(v, amount, output_encoded):
+    """What the last bits of the float32 blur may add to the error of a sharpened value `v`.
 
-    An edit returns `lin + M^-1 w (g(f+d) - g(f))`: terms of size ~2 that cancel when the edit pushes a channel
-    towards zero.  float32 keeps that sum to ~3e-7 (a relative 3e-8 in `f` already moves it by 2e-7); the reference
-    computes it in float64.  The edit's own sRGB encode and the output encode then multiply the error by their
-    slopes: 12.92 each near black (167 together below 0.2225 of final value), ~3 at mid grey, ~1 at the top."""
-    if n_edits == 0:
-        return np.zeros_like(np.asarray(v, np.float64))
+    The reference blurs L/100 in float32 (cv2.GaussianBlur on a float32 plane, editingTools.py:761-764), so the
+    last bits of the blurred value depend on the order and fusing of 13 x 2 multiply-adds: OpenCV's, the oracle's
+    and the kernel's all differ there, legitimately.  The sharpened lightness moves by amount / 50 times that
+    difference, the pixel by ~0.7 times that again, and the sRGB encodes that follow multiply it by their slopes
+    (12.92 each near black).  Everything else of the chain is held to the plain bars: where float32 cannot follow
+    the float64 reference - Lab edits that cancel a channel to almost zero - the library re-evaluates the pixel
+    in float64."""
     v = np.clip(np.asarray(v, np.float64), 0.0, 1.0)
     inner = lv.eotf_sRGB(v) if output_encoded else v
     slope = _encode_slope(lv.eotf_sRGB(inner))
     if output_encoded:
         slope = slope * _encode_slope(inner)
-    return n_edits * LAB_EDIT_ERR * slope
+    return BLUR_LAST_BITS * 0.7 * (amount / 50.0) * slope
 
 
 @pytest.mark.parametrize("seed", fuzz_seeds(200))
@@ -638,21 +640,18 @@ def test_random_stage_combinations(swatches, seed):
     M_T, M_R = swatches
     imgs, kw, recipe = fuzz_case(seed, M_T, M_R)
     neg, ccm_kw, gains, sh, usm, final_clip, out = recipe
-    n_edits = (sh is not None) + (usm is not None)
     got = run_chain_dev(imgs, **kw)
     for i in range(imgs.shape[0]):
         want = _oracle_chain(imgs[i], M_T, M_R, *recipe)
         if out in ("u16", "u8"):
+            # 1 step: an error below one step that crosses a truncation boundary
             scale = 65535.0 if out == "u16" else 255.0
             diff = np.abs(got[i].astype(np.int64) - want.astype(np.int64))
-            # 1 step for an error below one step that crosses a truncation boundary; the Lab-edit term only reaches
-            # a whole step on 16-bit output of dark channels (167 * 3e-7 * 65535 = 3.3 steps per edit at worst)
-            extra = _lab_edit_allowance(want / scale, n_edits, True) * scale
-            allowed = 1 + np.floor(F32_TOL * scale + extra).astype(np.int64)
-            assert np.all(diff <= allowed), (seed, list(kw.keys()), int(diff.max()))
+            extra = _blur_allowance(want / scale, usm[0], True) * scale if usm is not None else 0.0
+            assert np.all(diff <= 1 + np.floor(F32_TOL * scale + extra)), (seed, list(kw.keys()), int(diff.max()))
         else:
             # polynomial corrections of high order lose absolute accuracy with the size of their terms
             tol = F32_TOL * (1 if ccm_kw is None or ccm_kw.get("terms", 3) <= 3 and ccm_kw.get("degree", 1) <= 1 else 4)
             err = np.abs(got[i] - want)
-            allowed = tol + _lab_edit_allowance(want, n_edits, out == "f32_srgb")
-            assert np.all(err <= allowed), (seed, out, ccm_kw, sh, usm, len(gains), float(err.max()))
+            extra = _blur_allowance(want, usm[0], out == "f32_srgb") if usm is not None else 0.0
+            assert np.all(err <= tol + extra), (seed, out, ccm_kw, sh, usm, len(gains), float(err.max()))

@@ -27,6 +27,7 @@ def main():
             idx = np.unravel_index(np.argmax(d), d.shape)
             print(f"  image {i}: max |diff| {d.max():.6g} at {idx}: got {got[i][idx]!r} want {want[idx]!r}; "
                   f"input pixel {imgs[i][idx[0], idx[1]]}, want pixel {want[idx[0], idx[1]]}")
+            print(f"   pixel as computed: {got[i][idx[0], idx[1]]}")
             worst = np.argsort(d.ravel())[::-1][:5]
             print("   next worst:", [(np.unravel_index(k, d.shape), float(d.ravel()[k]), float(want.ravel()[k])) for k in worst])
 
