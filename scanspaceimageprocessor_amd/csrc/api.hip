@@ -384,27 +384,34 @@ int context_scratch(ss_ctx* c, const ChainParams& P, int batch, ChainScratch* ou
   int rc = grow(c, &c->ws_risk, &c->ws_risk_bytes, kScratchBitsAt + risk_record_bytes(P, batch));
   if (rc) return rc;
   out->ticket = c->usm_ticket;
-  out->map.any = (uint32_t*)c->ws_risk;
+  out->map.any = (uint32_t*)((char*)c->ws_risk + kScratchFlagsAt);  // (same layout as the static scratch)
   out->map.count = out->map.any + 1;
   out->map.bits = (unsigned long long*)((char*)c->ws_risk + kScratchBitsAt);
   return SS_OK;
 }
 
 // One chain launch (pointwise or tile kernel) and, for chains with a Lab edit, the float64 kernel behind it.
-int launch_chain_and_careful(ss_ctx* c, const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
+int launch_chain_and_careful(ss_ctx* c, const ChainParams& P_in, int batch, int out_kind, const float* src, void* dst,
                              const ChainScratch& S) {
+  ChainParams P = P_in;
   const bool careful = chain_needs_careful(P, out_kind);
   c->last_risk_count = careful ? S.map.count : nullptr;
-  if (careful) SS_HIP(c, hipMemsetAsync(S.map.any, 0, 256, c->stream));
-  hipError_t e = P.usm ? launch_usm(P, batch, out_kind, src, dst, S.ticket, S.map, c->stream)
-                       : launch_chain(P, batch, out_kind, src, dst, S.map, c->stream);
+  if (careful) {
+    P.risk_bits = S.map.bits;
+    P.risk_any = S.map.any;
+    P.risk_count = S.map.count;
+    // {any, count} and the record behind them
+    SS_HIP(c, hipMemsetAsync(S.map.any, 0, (kScratchBitsAt - kScratchFlagsAt) + risk_record_bytes(P, batch), c->stream));
+  }
+  hipError_t e = P.usm ? launch_usm(P, batch, out_kind, src, dst, S.ticket, c->stream)
+                       : launch_chain(P, batch, out_kind, src, dst, c->stream);
   // (SS_CAREFUL=0, a debugging aid: leave the recorded pixels as the float32 kernels left them - for chains with
   // an unsharp mask that is the stashed blur value, not a result)
   static const bool skip = [] {
     const char* v = getenv("SS_CAREFUL");
     return v && v[0] == '0';
   }();
-  if (e == hipSuccess && careful && !skip) e = launch_careful(P, batch, out_kind, src, dst, S.map, c->stream);
+  if (e == hipSuccess && careful && !skip) e = launch_careful(P, batch, out_kind, src, dst, c->stream);
   if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return SS_OK;
 }

@@ -35,7 +35,7 @@ __device__ __forceinline__ void store_one(void* dst_img, uint32_t px, const Px p
 
 template <int CCMC, bool SH, int OUT>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, const float* __restrict__ src,
-                                                    void* __restrict__ dst, const RiskMap Q) {
+                                                    void* __restrict__ dst) {
   constexpr int G = OutTraits<OUT>::G;
   constexpr int K = 4 / G;  // groups per lane per trip: 4 pixels in flight per lane
   __shared__ float4 M[ccm_needs_table<CCMC> ? SS_MAX_CCM_TERMS : 1];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
     bool flagged[4] = {false, false, false, false};
 #pragma unroll
     for (int q = 0; q < 4; q += 2) {
-      RiskT<v2f> risk = risk_init<OUT, v2f>();
+      RiskT<v2f> risk{};
       const Px2 o2 = finish<OUT, false, v2f>(
           front<CCMC, SH, false, v2f>(pair_px(Px{in[q].x, in[q].y, in[q].z}, Px{in[q + 1].x, in[q + 1].y, in[q + 1].z}), P,
                                       ip, M, SH ? &risk : nullptr),
@@ -96,10 +96,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
       res[q + 1] = px_hi(o2);
       if constexpr (SH && RiskCfg<OUT>::ENABLED) {
         // pixels whose shadows/highlights edit float32 cannot follow (see RiskCfg): recorded for the float64 kernel
-        if (risk.flags != 0u) {  // almost never
+        const bool big0 = risk_big<OUT>(risk.mx.x), big1 = risk_big<OUT>(risk.mx.y);
+        if (__ballot(big0 || big1) != 0ull) {  // a scalar branch, almost never taken
           const uint32_t p0 = base * G + q * 256 + threadIdx.x, p1 = p0 + 256;
-          flagged[q] = (risk.flags & 1u) && p0 < n;
-          flagged[q + 1] = (risk.flags & 2u) && p1 < n;
+          flagged[q] = big0 && risk_cancelled<OUT>(risk.mx.x, risk.o.r.x, risk.o.g.x, risk.o.b.x) && p0 < n;
+          flagged[q + 1] = big1 && risk_cancelled<OUT>(risk.mx.y, risk.o.r.y, risk.o.g.y, risk.o.b.y) && p1 < n;
         }
       }
       // long term lists: one pair's arithmetic at a time keeps the register count down (282 -> 102 vector
@@ -107,14 +108,18 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
       if constexpr (ccm_needs_table<CCMC>) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (SH && RiskCfg<OUT>::ENABLED) {
-      // lane t holds pixels t, t + 256, ... of the chunk: a wave's k-th pixels are 64 consecutive ones, one word
+      // Lane t holds pixels t, t + 256, ... of the chunk: a wave's k-th pixels are 64 consecutive ones, one word
+      // of the record (which the launcher has cleared).  Almost never taken.
+      if (__ballot(flagged[0] || flagged[1] || flagged[2] || flagged[3]) != 0ull) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned long long m = __ballot(flagged[k]);
-        const uint32_t first = base * G + k * 256 + (threadIdx.x & ~63u);  // a multiple of 64
-        if ((threadIdx.x & 63u) == 0 && first < n) {
-          Q.bits[(size_t)img * ((n + 63u) / 64u) + first / 64u] = m;
-          if (m != 0ull) *Q.any = 1u;
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long m = __ballot(flagged[k]);
+          const uint32_t first = base * G + k * 256 + (threadIdx.x & ~63u);  // a multiple of 64
+          if ((threadIdx.x & 63u) == 0 && m != 0ull) {
+            const ChainParams& Pr = kernarg_params();
+            Pr.risk_bits[(size_t)img * ((n + 63u) / 64u) + first / 64u] = m;
+            *Pr.risk_any = 1u;
+          }
         }
       }
     }
@@ -201,7 +206,7 @@ hipError_t launch_unpack_u16(const uint16_t* src, float* dst, uint64_t n, hipStr
 
 template <int CCMC, bool SH>
 static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                   const RiskMap& Q, hipStream_t st) {
+                                   hipStream_t st) {
   auto grid_for = [&](int G) {
     const uint32_t K = 4 / G;
     const uint64_t groups = (uint64_t)P.n_px / G;
@@ -215,19 +220,19 @@ static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind
   };
   switch (out_kind) {
     case SS_OUT_F32_LINEAR:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_LINEAR>), grid_for(1), dim3(256), 0, st, P, src, dst, Q);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_LINEAR>), grid_for(1), dim3(256), 0, st, P, src, dst);
       break;
     case SS_OUT_F32_SRGB:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_SRGB>), grid_for(1), dim3(256), 0, st, P, src, dst, Q);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_F32_SRGB>), grid_for(1), dim3(256), 0, st, P, src, dst);
       break;
     case SS_OUT_U16_SRGB:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U16_SRGB>), grid_for(2), dim3(256), 0, st, P, src, dst, Q);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U16_SRGB>), grid_for(2), dim3(256), 0, st, P, src, dst);
       break;
     case SS_OUT_U8_SRGB:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_SRGB>), grid_for(4), dim3(256), 0, st, P, src, dst, Q);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_SRGB>), grid_for(4), dim3(256), 0, st, P, src, dst);
       break;
     case SS_OUT_U8_LINEAR:
-      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_LINEAR>), grid_for(4), dim3(256), 0, st, P, src, dst, Q);
+      hipLaunchKernelGGL((chain_kernel<CCMC, SH, SS_OUT_U8_LINEAR>), grid_for(4), dim3(256), 0, st, P, src, dst);
       break;
     default:
       return hipErrorInvalidValue;
@@ -237,18 +242,17 @@ static hipError_t launch_chain_out(const ChainParams& P, int batch, int out_kind
 
 template <int CCMC>
 static hipError_t launch_chain_sh(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                  const RiskMap& Q, hipStream_t st) {
-  return P.sh ? launch_chain_out<CCMC, true>(P, batch, out_kind, src, dst, Q, st)
-              : launch_chain_out<CCMC, false>(P, batch, out_kind, src, dst, Q, st);
+                                  hipStream_t st) {
+  return P.sh ? launch_chain_out<CCMC, true>(P, batch, out_kind, src, dst, st)
+              : launch_chain_out<CCMC, false>(P, batch, out_kind, src, dst, st);
 }
 
-hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, const RiskMap& Q,
-                        hipStream_t st) {
-  if (P.ccm_kind == SS_CCM_NONE) return launch_chain_sh<CCM_NONE>(P, batch, out_kind, src, dst, Q, st);
-  if (P.ccm_terms == 3) return launch_chain_sh<CCM_LIN3>(P, batch, out_kind, src, dst, Q, st);
-  if (P.ccm_terms <= 8) return launch_chain_sh<CCM_SMALL>(P, batch, out_kind, src, dst, Q, st);
-  if (P.ccm_kind == SS_CCM_CHEUNG) return launch_chain_sh<CCM_CHEUNG>(P, batch, out_kind, src, dst, Q, st);
-  return launch_chain_sh<CCM_ROOT>(P, batch, out_kind, src, dst, Q, st);
+hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {
+  if (P.ccm_kind == SS_CCM_NONE) return launch_chain_sh<CCM_NONE>(P, batch, out_kind, src, dst, st);
+  if (P.ccm_terms == 3) return launch_chain_sh<CCM_LIN3>(P, batch, out_kind, src, dst, st);
+  if (P.ccm_terms <= 8) return launch_chain_sh<CCM_SMALL>(P, batch, out_kind, src, dst, st);
+  if (P.ccm_kind == SS_CCM_CHEUNG) return launch_chain_sh<CCM_CHEUNG>(P, batch, out_kind, src, dst, st);
+  return launch_chain_sh<CCM_ROOT>(P, batch, out_kind, src, dst, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -257,9 +261,9 @@ hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const flo
 
 // One workgroup takes 256 words of the record at a time, counts their bits, and deals the recorded pixels out
 // evenly over its threads (prefix sums in LDS), so a word with many recorded pixels does not hold a wave up.
-__global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, const RiskMap Q, int layout, int batch,
+__global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, int layout, int batch,
                                                       const float* __restrict__ src, void* __restrict__ dst, int out_kind) {
-  if (*Q.any == 0u) return;
+  if (*P.risk_any == 0u) return;
   const ChainParams* Pk = (const ChainParams*)__builtin_amdgcn_kernarg_segment_ptr();  // P is the first argument
   const bool enc = out_kind != SS_OUT_F32_LINEAR && out_kind != SS_OUT_U8_LINEAR;
   const int W = P.width, H = P.height;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, const
   __shared__ uint32_t start[257];
   for (size_t chunk = (size_t)blockIdx.x * 256; chunk < n_words; chunk += (size_t)gridDim.x * 256) {
     const size_t g = chunk + threadIdx.x;
-    const unsigned long long w = g < n_words ? Q.bits[g] : 0ull;
+    const unsigned long long w = g < n_words ? P.risk_bits[g] : 0ull;
     if (__syncthreads_or(w != 0ull) == 0) continue;
     words[threadIdx.x] = w;
     // inclusive scan of the bit counts
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, const
       __syncthreads();
     }
     const uint32_t total = start[256];
-    if (threadIdx.x == 0) atomicAdd(Q.count, total);
+    if (threadIdx.x == 0) atomicAdd(P.risk_count, total);
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
       // the word that holds the i-th recorded pixel of the chunk: start[j] <= i < start[j + 1]
       uint32_t lo = 0, hi = 256;
@@ -331,13 +335,12 @@ __global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, const
   }
 }
 
-hipError_t launch_careful(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, const RiskMap& Q,
-                          hipStream_t st) {
+hipError_t launch_careful(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {
   const int layout = P.usm ? RISK_TILES : RISK_LINEAR;
   const size_t n_words = risk_words_per_image(layout, P.height, P.width) * (size_t)batch;
   size_t blocks = (n_words + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(careful_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, Q, layout, batch, src, dst, out_kind);
+  hipLaunchKernelGGL(careful_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, layout, batch, src, dst, out_kind);
   return hipGetLastError();
 }
 

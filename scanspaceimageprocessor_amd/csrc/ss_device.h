@@ -57,7 +57,21 @@ struct ChainParams {
   float sh_shadow_amount, sh_highlight_amount, sh_falloff, usm_amount, usm_threshold;
   float sh_risk_bound;
   float ccm_lo[SS_MAX_CCM_TERMS][4];
+  // Record of the pixels to evaluate again (see RiskMap below): set by the launcher, read in the rare branch only
+  unsigned long long* risk_bits;
+  uint32_t* risk_any;
+  uint32_t* risk_count;
 };
+
+// The kernel's parameter block as its kernel-argument segment holds it (the block is every kernel's FIRST argument),
+// behind a pointer the compiler cannot see through: scalars read through it are loaded where they are used instead
+// of living in scalar registers (spilled to vector lanes, each reload a vector instruction) across a whole loop.
+__device__ __forceinline__ const ChainParams& kernarg_params() {
+  typedef const __attribute__((address_space(4))) ChainParams* KernargParams;
+  KernargParams k = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return *(const ChainParams*)k;
+}
 
 // sRGB <-> XYZ of colour-science's sRGB colourspace: IEC 61966-2-1:1999 gives both matrices to four decimals
 // and colour carries both as given, so they are not an exact inverse pair (XYZ->RGB . RGB->XYZ = I + E with
@@ -268,47 +282,29 @@ template <int OUT>
 struct RiskCfg {
   static constexpr bool ENCODED = OUT == SS_OUT_F32_SRGB || OUT == SS_OUT_U16_SRGB;
   static constexpr bool ENABLED = OUT == SS_OUT_F32_LINEAR || ENCODED;
-  static constexpr float MIN_MX = ENCODED ? 0.05f / 3.3f : 1.29f / 3.3f;
+  static constexpr float MIN_MX = ENCODED ? 0.1f / 3.3f : 1.29f / 3.3f;
   static constexpr float RATIO = ENCODED ? 60.0f / 3.3f : 250.0f / 3.3f;
 };
 constexpr float kRiskBelowZero = -4.0e-6f;
 
-// What an edit reports: on entry `mx` holds what an earlier edit of the same pixel contributed, on return the
-// total; `flags` (bit 0: the pixel, or the first of a pair; bit 1: the second) says which pixels are at risk.  The
-// flags are only worked out when `min_mx` is finite (the caller's output needs them), and then only by waves that
-// hold a pixel with mx > min_mx at all: almost none.
+// What an edit reports: its `mx` (the caller adds what an earlier edit of the same pixel contributed) and the
+// edited linear pixel `o` before it is encoded.  The caller decides at the end of its pixel, in a branch
+// that only waves holding a pixel with a large edit take (almost none), which pixels are at risk.
 template <class V>
 struct RiskT {
   V mx;
-  float min_mx, inv_ratio;
-  uint32_t flags;
+  PxT<V> o;
 };
-template <int OUT, class V>
-__device__ __forceinline__ RiskT<V> risk_init(V carried = (V)(0.0f)) {
-  return RiskT<V>{carried, RiskCfg<OUT>::ENABLED ? RiskCfg<OUT>::MIN_MX : __builtin_inff(), 1.0f / RiskCfg<OUT>::RATIO, 0u};
-}
-// only the size of the edit is wanted (it is handed to a later stage)
-template <class V>
-__device__ __forceinline__ RiskT<V> risk_size_only() {
-  return RiskT<V>{(V)(0.0f), __builtin_inff(), 0.0f, 0u};
-}
 __device__ __forceinline__ bool risk_channel(float o, float lim) { return o > kRiskBelowZero && o < lim; }
-__device__ __forceinline__ void risk_eval(RiskT<float>& k, float r, float g, float b) {
-  if (!(k.min_mx < __builtin_inff())) return;
-  const bool big = k.mx > k.min_mx;
-  if (__ballot(big) != 0ull) {
-    const float lim = k.mx * k.inv_ratio;
-    if (big && (risk_channel(r, lim) || risk_channel(g, lim) || risk_channel(b, lim))) k.flags = 1u;
-  }
+template <int OUT>
+__device__ __forceinline__ bool risk_big(float mx) {
+  return RiskCfg<OUT>::ENABLED && mx > RiskCfg<OUT>::MIN_MX;
 }
-__device__ __forceinline__ void risk_eval(RiskT<v2f>& k, v2f r, v2f g, v2f b) {
-  if (!(k.min_mx < __builtin_inff())) return;
-  const bool big0 = k.mx.x > k.min_mx, big1 = k.mx.y > k.min_mx;
-  if (__ballot(big0 || big1) != 0ull) {
-    const float lim0 = k.mx.x * k.inv_ratio, lim1 = k.mx.y * k.inv_ratio;
-    if (big0 && (risk_channel(r.x, lim0) || risk_channel(g.x, lim0) || risk_channel(b.x, lim0))) k.flags |= 1u;
-    if (big1 && (risk_channel(r.y, lim1) || risk_channel(g.y, lim1) || risk_channel(b.y, lim1))) k.flags |= 2u;
-  }
+// (call where risk_big holds)
+template <int OUT>
+__device__ __forceinline__ bool risk_cancelled(float mx, float r, float g, float b) {
+  const float lim = mx * (1.0f / RiskCfg<OUT>::RATIO);
+  return risk_channel(r, lim) || risk_channel(g, lim) || risk_channel(b, lim);
 }
 
 // A shadows/highlights edit in front of the unsharp mask hands its mx to the sharpen stage, which sees the pixel
@@ -329,9 +325,9 @@ __device__ __forceinline__ float risk_carried(float c0, float c1, float c2, floa
   return l == 7 ? bound_max : __uint_as_float((l + 121u) << 23);  // 2^(l - 6)
 }
 
-// Record of the pixels to evaluate again: one bit per pixel, written by the float32 kernels as whole 64-bit words
-// (a wave's ballot), every word of the record on every launch, so it needs no clearing and holds any number of
-// pixels.  Two layouts, after how the kernels walk an image:
+// Record of the pixels to evaluate again: one bit per pixel, cleared by the launcher; the float32 kernels write a
+// word only when it has a bit set, as a whole 64-bit word (a wave's ballot: no atomics), and it holds any number
+// of pixels.  Two layouts, after how the kernels walk an image:
 //   RISK_LINEAR  (pointwise kernel)  word w of an image = pixels [64 w, 64 w + 64), bit b = pixel 64 w + b;
 //   RISK_TILES   (tile kernel)       words (y * tiles_x + t) * 2 + e, e = 0 / 1, of an image = row y of tile column t:
 //                                    bit b of word e = pixel x = 128 t + 2 b + e.
@@ -384,8 +380,8 @@ __device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V
   o.g = mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, ug)));
   o.b = mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, ub)));
   if (risk) {
-    risk->mx = risk->mx + vmax3abs(dx, dy, dz);
-    risk_eval(*risk, o.r, o.g, o.b);
+    risk->mx = vmax3abs(dx, dy, dz);
+    risk->o = o;
   }
   return o;
 }

@@ -10,21 +10,19 @@ namespace ss {
 
 // ---- chain.hip ---------------------------------------------------------------------------------
 // Pointwise fused chain (stages 1-4, 6, 7) over `batch` images.
-// Q: record of the pixels to evaluate again in float64 (chains with a Lab edit; see RiskCfg, RiskMap in ss_device.h)
-hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, const RiskMap& Q,
-                        hipStream_t st);
+// (chains with a Lab edit record the pixels to evaluate again in float64 at P.risk_bits; see RiskCfg, RiskMap)
+hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st);
 // does a chain with these parameters and this output kind ever queue pixels?
 bool chain_needs_careful(const ChainParams& P, int out_kind);
 // float64 re-evaluation of what the launch before it recorded (same P, batch, src, dst), overwriting those output
 // pixels; the record's layout follows from P.usm (tile kernel) or not (pointwise kernel)
-hipError_t launch_careful(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, const RiskMap& Q,
-                          hipStream_t st);
+hipError_t launch_careful(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st);
 // Fused chain with the unsharp mask (stage 5): tile + halo recompute, separable blur in LDS.
 // Colour correction: none or the 3-term matrix only (callers run larger expansions as a pointwise pass first).
 // `ticket`: eight uint32 of device memory owned by the caller (the per-XCD segment counters); launches that share
 // them must be stream-ordered
 hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, uint32_t* ticket,
-                      const RiskMap& Q, hipStream_t st);
+                      hipStream_t st);
 
 // ---- stats.hip ---------------------------------------------------------------------------------
 struct PercentileWork {

@@ -103,8 +103,7 @@ extern "C" int ss_debug_usm_trace(void* out) {
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>
 __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const StripWalk T,
-                                                     const float* __restrict__ src, void* __restrict__ dst,
-                                                     const RiskMap Q) {
+                                                     const float* __restrict__ src, void* __restrict__ dst) {
   constexpr int TW = USM_TW, TH = USM_TH, NT = USM_NT;
   extern __shared__ __attribute__((aligned(16))) float S[];
   __shared__ float4 M[ccm_needs_table<CCMC> ? SS_MAX_CCM_TERMS : 1];
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         Px2 o = Px2{blur + v2f{c0.x, c0.y}, Ln + v2f{c1.x, c1.y}, v2f{c2.x, c2.y}};
 #else
         Px2 o;
-        RiskT<v2f> risk = risk_init<OUT, v2f>();
+        RiskT<v2f> risk{};
         if (!PLAIN && P.lab_io) {
           const Lab2 q = usm_on_lab<PLAIN, v2f>(Ln, v2f{c1.x, c1.y}, v2f{c2.x, c2.y}, blur, P);
           o = Px2{q.L, q.a, q.b};
@@ -351,21 +350,28 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
           // phase 1 hands the size of a shadows/highlights edit over in the signs of the channel values (which
           // that stage has clipped to [0, 1]; without the stage a value may be negative in its own right)
           Px2 lin{v2f{c0.x, c0.y}, v2f{c1.x, c1.y}, v2f{c2.x, c2.y}};
+          v2f carried = v2f{0.0f, 0.0f};
           if (P.sh) {
-            risk.mx = v2f{risk_carried(c0.x, c1.x, c2.x, P.sh_risk_bound), risk_carried(c0.y, c1.y, c2.y, P.sh_risk_bound)};
+            carried = v2f{risk_carried(c0.x, c1.x, c2.x, P.sh_risk_bound), risk_carried(c0.y, c1.y, c2.y, P.sh_risk_bound)};
             lin = Px2{v2f{fabsf(c0.x), fabsf(c0.y)}, v2f{fabsf(c1.x), fabsf(c1.y)}, v2f{fabsf(c2.x), fabsf(c2.y)}};
           }
           o = usm_on_rgb<PLAIN, v2f>(lin, Ln, blur, P, &risk);
+          risk.mx = risk.mx + carried;
         }
         // the sharpened pixel is in [0,1]; the LAB branch has no final clip: either way the clip stage is a no-op here
         o = finish<OUT, true, v2f>(o, P);
         // Pixels whose Lab edits float32 cannot follow (see RiskCfg) are recorded for the float64 kernel, their
-        // blurred lightness waiting in the first four bytes of their own output slot.  Every lane of the wave is
-        // here (a wave works through whole tile rows), so the wave's record of the row is two ballots.
+        // blurred lightness waiting in the first four bytes of their own output slot.  A wave works through whole
+        // tile rows, so every lane with such a pixel in this row is in this branch now: two ballots are the row's
+        // two words of the record, which the launcher has cleared.  Almost never taken.
         if constexpr (RiskCfg<OUT>::ENABLED) {
-          const int gy = y0 + ly, gx = x0 + px;
-          const bool f0 = (risk.flags & 1u) && gy < H && gx < W, f1 = (risk.flags & 2u) && gy < H && gx + 1 < W;
-          if (risk.flags != 0u) {  // almost never
+          const bool big0 = risk_big<OUT>(risk.mx.x), big1 = risk_big<OUT>(risk.mx.y);
+          if (__ballot(big0 || big1) != 0ull) {        // a scalar branch: the whole wave skips it
+            const ChainParams& Pr = kernarg_params();  // (nothing this branch needs stays in registers outside it)
+            const int Wr = Pr.width, Hr = Pr.height;
+            const int gy = y0 + ly, gx = x0 + px;
+            const bool f0 = big0 && risk_cancelled<OUT>(risk.mx.x, risk.o.r.x, risk.o.g.x, risk.o.b.x) && gy < Hr && gx < Wr;
+            const bool f1 = big1 && risk_cancelled<OUT>(risk.mx.y, risk.o.r.y, risk.o.g.y, risk.o.b.y) && gy < Hr && gx + 1 < Wr;
             // what the slot's first two values must be for the stored bytes to be the float's bits
             auto stash = [](float Lb, float r, float g) -> float2 {
               if constexpr (OUT == SS_OUT_U16_SRGB) {  // two 16-bit codes
@@ -383,12 +389,12 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
               const float2 k = stash(blur.y, o.r.y, o.g.y);
               o.r.y = k.x, o.g.y = k.y;
             }
-          }
-          const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
-          if ((px == 0) && gy < H) {
-            const size_t w = (((size_t)cur.img * H + gy) * T.tiles_x + x0 / TW) * 2;
-            *reinterpret_cast<ulonglong2*>(Q.bits + w) = ulonglong2{m0, m1};
-            if ((m0 | m1) != 0ull) *Q.any = 1u;
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+            if ((m0 | m1) != 0ull && px == 0) {  // lane 0: every lane of the wave is here
+              const size_t w = (((size_t)cur.img * Hr + gy) * ((Wr + TW - 1) / TW) + x0 / TW) * 2;
+              *reinterpret_cast<ulonglong2*>(Pr.risk_bits + w) = ulonglong2{m0, m1};
+              *Pr.risk_any = 1u;
+            }
           }
         }
 #endif
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #ifdef SS_ABL_NO_P1  // timing experiment: phase 1 without its arithmetic
         return Slot{px.x, px};
 #else
-        RiskT<float> risk = risk_size_only<float>();
+        RiskT<float> risk{};
         const Px lin = front_decoded<CCMC, PLAIN, float>(Px{px.x, px.y, px.z}, P, ip, M, PLAIN ? nullptr : &risk);
         if (!PLAIN && P.lab_io) return Slot{lin.r * 0.01f, F3{lin.r, lin.g, lin.b}};
         const float r = lin.r, g = lin.g, b = lin.b;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         qa = Slot{pa.x, pa};
         qb = Slot{pb.x, pb};
 #else
-        RiskT<v2f> risk = risk_size_only<v2f>();
+        RiskT<v2f> risk{};
         const Px2 p = front_decoded<CCMC, PLAIN, v2f>(Px2{v2f{pa.x, pb.x}, v2f{pa.y, pb.y}, v2f{pa.z, pb.z}}, P, ip, M,
                                                       PLAIN ? nullptr : &risk);
         if (!PLAIN && P.lab_io) {
@@ -671,7 +677,7 @@ static size_t usm_lds_bytes(int r) {
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>
 static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* src, void* dst, uint32_t* ticket,
-                                  const RiskMap& Q, hipStream_t st) {
+                                  hipStream_t st) {
   const size_t lds = usm_lds_bytes(P.usm_r);
   auto kern = usm_kernel<R_T, CCMC, OUT, PLAIN>;
   if (lds > 64 * 1024) {  // sticky per device and kernel; cheap enough to repeat
@@ -699,24 +705,24 @@ static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* s
   const unsigned blocks = (unsigned)(n_segments < cap ? n_segments : cap);
   hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ticket), 0, 8, st);
   if (me != hipSuccess) return me;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(USM_NT), lds, st, P, T, src, dst, Q);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(USM_NT), lds, st, P, T, src, dst);
   return hipGetLastError();
 }
 
 template <int R_T, int CCMC, bool PLAIN>
 static hipError_t launch_usm_out(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                 uint32_t* ticket, const RiskMap& Q, hipStream_t st) {
+                                 uint32_t* ticket, hipStream_t st) {
   switch (out_kind) {
     case SS_OUT_F32_LINEAR:
-      return launch_usm_one<R_T, CCMC, SS_OUT_F32_LINEAR, PLAIN>(P, batch, src, dst, ticket, Q, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_F32_LINEAR, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_F32_SRGB:
-      return launch_usm_one<R_T, CCMC, SS_OUT_F32_SRGB, PLAIN>(P, batch, src, dst, ticket, Q, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_F32_SRGB, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_U16_SRGB:
-      return launch_usm_one<R_T, CCMC, SS_OUT_U16_SRGB, PLAIN>(P, batch, src, dst, ticket, Q, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_U16_SRGB, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_U8_SRGB:
-      return launch_usm_one<R_T, CCMC, SS_OUT_U8_SRGB, PLAIN>(P, batch, src, dst, ticket, Q, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_U8_SRGB, PLAIN>(P, batch, src, dst, ticket, st);
     case SS_OUT_U8_LINEAR:
-      return launch_usm_one<R_T, CCMC, SS_OUT_U8_LINEAR, PLAIN>(P, batch, src, dst, ticket, Q, st);
+      return launch_usm_one<R_T, CCMC, SS_OUT_U8_LINEAR, PLAIN>(P, batch, src, dst, ticket, st);
     default:
       return hipErrorInvalidValue;
   }
@@ -724,26 +730,26 @@ static hipError_t launch_usm_out(const ChainParams& P, int batch, int out_kind, 
 
 template <int R_T>
 static hipError_t launch_usm_ccm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst,
-                                 uint32_t* ticket, const RiskMap& Q, hipStream_t st) {
+                                 uint32_t* ticket, hipStream_t st) {
   const bool lin3 = P.ccm_kind != SS_CCM_NONE && P.ccm_terms == 3;
   // the worker's chart path without further adjustments: CCM, one gain stage, sharpen
   const bool plain = lin3 && !P.neg && P.n_gain == 1 && !P.sh && !P.lab_io && P.usm_thr == 0.0f;
-  if (plain) return launch_usm_out<R_T, CCM_LIN3, true>(P, batch, out_kind, src, dst, ticket, Q, st);
-  if (lin3) return launch_usm_out<R_T, CCM_LIN3, false>(P, batch, out_kind, src, dst, ticket, Q, st);
+  if (plain) return launch_usm_out<R_T, CCM_LIN3, true>(P, batch, out_kind, src, dst, ticket, st);
+  if (lin3) return launch_usm_out<R_T, CCM_LIN3, false>(P, batch, out_kind, src, dst, ticket, st);
   // colour corrections with more terms run as a pointwise pass of their own in front (see ss_chain_run)
   if (P.ccm_kind != SS_CCM_NONE) return hipErrorInvalidValue;
   // the worker's no-chart path with exposure and sharpen only (and the second pass of a staged chain)
   const bool plain_none = !P.neg && P.n_gain == 1 && !P.sh && !P.lab_io && P.usm_thr == 0.0f;
-  if (plain_none) return launch_usm_out<R_T, CCM_NONE, true>(P, batch, out_kind, src, dst, ticket, Q, st);
-  return launch_usm_out<R_T, CCM_NONE, false>(P, batch, out_kind, src, dst, ticket, Q, st);
+  if (plain_none) return launch_usm_out<R_T, CCM_NONE, true>(P, batch, out_kind, src, dst, ticket, st);
+  return launch_usm_out<R_T, CCM_NONE, false>(P, batch, out_kind, src, dst, ticket, st);
 }
 
 hipError_t launch_usm(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, uint32_t* ticket,
-                      const RiskMap& Q, hipStream_t st) {
+                      hipStream_t st) {
   if (P.usm_r < 1 || P.usm_r > SS_MAX_USM_RADIUS) return hipErrorInvalidValue;
-  if (P.usm_r == 3) return launch_usm_ccm<3>(P, batch, out_kind, src, dst, ticket, Q, st);
-  if (P.usm_r == 6) return launch_usm_ccm<6>(P, batch, out_kind, src, dst, ticket, Q, st);
-  return launch_usm_ccm<0>(P, batch, out_kind, src, dst, ticket, Q, st);
+  if (P.usm_r == 3) return launch_usm_ccm<3>(P, batch, out_kind, src, dst, ticket, st);
+  if (P.usm_r == 6) return launch_usm_ccm<6>(P, batch, out_kind, src, dst, ticket, st);
+  return launch_usm_ccm<0>(P, batch, out_kind, src, dst, ticket, st);
 }
 
 }  // namespace ss
