@@ -20,7 +20,17 @@
 namespace ss {
 
 constexpr int USM_TW = 128;  // tile width: 64 lanes x 2 adjacent pixels
-constexpr int USM_TH = 24;   // tile height
+// SS_USM_MFMA: both blur passes on the matrix pipe, 16-row tiles (see the kernel); else the vector form, 24-row tiles
+#ifdef SS_USM_MFMA
+#define SS_USM_TH 16
+constexpr bool USM_MFMA_BUILD = true;
+#else
+constexpr bool USM_MFMA_BUILD = false;
+#endif
+#ifndef SS_USM_TH
+#define SS_USM_TH 24
+#endif
+constexpr int USM_TH = SS_USM_TH;  // tile height
 #ifndef SS_USM_NT
 #define SS_USM_NT 512
 #endif
@@ -127,6 +137,27 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   constexpr int CP = TH * TW;             // plane pitch
   const int W = P.width, H = P.height;
   const int tid = threadIdx.x;
+  // Both passes of the separable blur on the matrix pipe (v_mfma_f32_16x16x4_f32: float32 in, float32 accumulate, one
+  // fused multiply-add per term in k order, i.e. the fmaf chain of the vector form bit for bit), which issues
+  // beside the vector ALU that limits this kernel.  A 16 x 16 block of outputs is the product of a 16 x (16 + 2r)
+  // band matrix of taps with a (16 + 2r) x 16 block of the plane; 16-row tiles give every wave one block per pass.
+  constexpr bool MFMA = USM_MFMA_BUILD && R_T != 0 && !ccm_needs_table<CCMC> && TH == 16 && NT == 512 && TW == 128;
+  constexpr int KS = (16 + 2 * (R_T ? R_T : 1) + 3) / 4;  // k steps of 4 per block
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  float band[KS];  // lane l holds w(4 s + l / 16 - l % 16): the band matrix as the A (row pass) / B (column pass) operand
+  if constexpr (MFMA) {
+    const float* taps = kernarg_params().taps;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int j = 4 * s + ((tid & 63) >> 4) - (tid & 15);
+      band[s] = (j >= 0 && j <= 2 * R_T) ? taps[j <= R_T ? j : 2 * R_T - j] : 0.0f;
+    }
+    // zero-weight terms still multiply what they read: every word of the planes must be a finite number from the
+    // start (padding columns are never written afterwards)
+    const int n_lds = (TH + 2 * R_T) * (((TW + 2 * R_T + 3) & ~3) + TW) + 3 * TH * TW;
+    for (int i = tid; i < n_lds; i += NT) S[i] = 0.0f;
+    __syncthreads();
+  }
   // Rows every tile computes itself: LDS rows [2r, PH) ("new rows", TH of them: image rows y0+r ... y0+TH+r-1).
   // Thread -> slot map of the new rows, affine in the slot number k so that no per-slot index lives in a
   // register: MAIN slots cover the TW tile columns (row 4k + tid/128, column tid%128 at NT = 512), one SIDE
@@ -164,7 +195,11 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   // living in scalar registers, spilled to vector lanes, across the whole walk.  (The parameter block is the
   // kernel's first argument: offset 0 of the argument segment.)
   auto params_now = [&]() -> const ChainParams& {
+#ifdef SS_PLAIN_KERNARG
+    if constexpr (true) {
+#else
     if constexpr (!PLAIN) {  // (the plain chain uses few enough parameters to keep them)
+#endif
       typedef const __attribute__((address_space(4))) ChainParams* KernargParams;
       KernargParams k = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(k));
@@ -279,7 +314,19 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 
       // ---- phase 2: row pass over the rows phase 1 has just written ----
       const int row_begin = first ? 0 : 2 * r;
-      const int n_items = (PH - row_begin) * (TW / 4);
+      const int n_items = MFMA ? 0 : (PH - row_begin) * (TW / 4);
+      if constexpr (MFMA) {
+        // wave w: columns [16 w, 16 w + 16) of the new rows [2r, 2r + 16); a first tile also of rows [0, 16)
+        const int t2 = fresh_tid();
+        const int lane = t2 & 63, c0 = (t2 >> 6) * 16;
+        for (int rb = first ? 0 : 2 * r; rb <= 2 * r; rb += 2 * r) {
+          const float* bp = Lt + (rb + (lane & 15)) * PW + c0 + (lane >> 4);
+          v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(band[s2], bp[4 * s2], acc, 0, 0, 0);
+          *reinterpret_cast<float4*>(Ht + (rb + (lane & 15)) * TW + c0 + 4 * (lane >> 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+      }
 #ifdef SS_ABL_NO_P2
       for (int item = tid; item < 0; item += NT) {
 #else
@@ -361,9 +408,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         // the sharpened pixel is in [0,1]; the LAB branch has no final clip: either way the clip stage is a no-op here
         o = finish<OUT, true, v2f>(o, P);
         // Pixels whose Lab edits float32 cannot follow (see RiskCfg) are recorded for the float64 kernel, their
-        // blurred lightness waiting in the first four bytes of their own output slot.  A wave works through whole
-        // tile rows, so every lane with such a pixel in this row is in this branch now: two ballots are the row's
-        // two words of the record, which the launcher has cleared.  Almost never taken.
+        // blurred lightness waiting in the first four bytes of their own output slot.  Almost never taken.
         if constexpr (RiskCfg<OUT>::ENABLED) {
           const bool big0 = risk_big<OUT>(risk.mx.x), big1 = risk_big<OUT>(risk.mx.y);
           if (__ballot(big0 || big1) != 0ull) {        // a scalar branch: the whole wave skips it
@@ -389,12 +434,11 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
               const float2 k = stash(blur.y, o.r.y, o.g.y);
               o.r.y = k.x, o.g.y = k.y;
             }
-            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
-            if ((m0 | m1) != 0ull && px == 0) {  // lane 0: every lane of the wave is here
-              const size_t w = (((size_t)cur.img * Hr + gy) * ((Wr + TW - 1) / TW) + x0 / TW) * 2;
-              *reinterpret_cast<ulonglong2*>(Pr.risk_bits + w) = ulonglong2{m0, m1};
-              *Pr.risk_any = 1u;
-            }
+            // (the record was cleared by the launcher; this branch is rare enough for an atomic per pixel)
+            const size_t w = (((size_t)cur.img * Hr + gy) * ((Wr + TW - 1) / TW) + x0 / TW) * 2;
+            if (f0) atomicOr(Pr.risk_bits + w, 1ull << (px >> 1));
+            if (f1) atomicOr(Pr.risk_bits + w + 1, 1ull << (px >> 1));
+            if (f0 || f1) *Pr.risk_any = 1u;
           }
         }
 #endif
@@ -404,7 +448,19 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         usm_store_pair<OUT, PLAIN>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
 #endif
       };
-      if constexpr (R_T != 0) {
+      if constexpr (MFMA) {
+        // wave w: the 16 x 16 block of columns [16 w, 16 w + 16); lane l ends up with the blurred values of row
+        // l % 16, columns 16 w + 4 (l / 16) ... + 3: two pixel pairs
+        const int t3 = fresh_tid();
+        const int lane = t3 & 63, c0 = (t3 >> 6) * 16;
+        const float* ap = Ht + (lane >> 4) * TW + c0 + (lane & 15);
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s2 * TW], band[s2], acc, 0, 0, 0);
+        pair_out(lane & 15, c0 + 4 * (lane >> 4), v2f{acc[0], acc[1]});
+        __builtin_amdgcn_sched_barrier(0);
+        pair_out(lane & 15, c0 + 4 * (lane >> 4) + 2, v2f{acc[2], acc[3]});
+      } else if constexpr (R_T != 0) {
         // a thread owns one pixel-pair column and RUN consecutive rows: the RUN + 2r row-filtered values it
         // needs are read once, all reads in flight together, and every output reuses 2r of them
         constexpr int RUN = TH / (NT / (TW / 2));
