@@ -87,6 +87,28 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
   }
 }
 
+// The same for a pair that is known to lie inside the image with its 12-byte slot 4-byte aligned (a tile that the
+// image covers whole, in an image of even width): no bounds tests, no alignment test, a 32-bit byte offset on the
+// image's base address (an image has at most 2^28 pixels).
+template <int OUT, bool UNIT>
+__device__ __forceinline__ void usm_store_pair_inside(void* dst_img, int W, int y, int x, const Px o0, const Px o1) {
+  auto q16 = [](float v) -> uint32_t { return UNIT ? quant16_unit(v) : quant16(v); };
+  const uint32_t px = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+  if constexpr (OUT == SS_OUT_F32_LINEAR || OUT == SS_OUT_F32_SRGB) {
+    F3* d = reinterpret_cast<F3*>(reinterpret_cast<char*>(dst_img) + px * 12u);
+    store_stream(d, F3{o0.r, o0.g, o0.b});
+    store_stream(d + 1, F3{o1.r, o1.g, o1.b});
+  } else if constexpr (OUT == SS_OUT_U16_SRGB) {
+    U3 q;
+    q.x = q16(o0.r) | (q16(o0.g) << 16);
+    q.y = q16(o0.b) | (q16(o1.r) << 16);
+    q.z = q16(o1.g) | (q16(o1.b) << 16);
+    store_stream(reinterpret_cast<U3*>(reinterpret_cast<char*>(dst_img) + px * 6u), q);
+  } else {
+    usm_store_pair<OUT, UNIT>(dst_img, W, 1 << 30, y, x, o0, o1);
+  }
+}
+
 // R_T : compile-time blur radius (3 <-> sigma 1, 6 <-> sigma 2), 0 = runtime radius P.usm_r.
 // CCMC: CCM_LIN3 for the reference's 3-term correction, CCM_NONE for chains without one.
 //
@@ -232,14 +254,18 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
     t.first = true;
     return t;
   };
-  // source pixel index of LDS slot (ly, lx) of the tile at (x0, y0)
+  // source pixel of LDS slot (ly, lx) of the tile at (x0, y0), as a BYTE offset into the image (an image has at
+  // most 2^28 pixels of 12 bytes: 32 bits hold it, and the load takes the image's base address as a scalar)
   auto slot_src = [&](int x0, int y0, bool interior, int ly, int lx) -> uint32_t {
     int py = y0 - r + ly, px = x0 - r + lx;
     if (!interior) {
       py = reflect_coord(py, H);
       px = reflect_coord(px, W);
     }
-    return (uint32_t)py * W + px;
+    return ((uint32_t)py * W + px) * 12u;
+  };
+  auto pixel_at = [](const F3* image, uint32_t byte_offset) -> F3 {
+    return *reinterpret_cast<const F3*>(reinterpret_cast<const char*>(image) + byte_offset);
   };
   auto is_interior = [&](int x0, int y0) -> bool {
     // tiles whose halo stays inside the image skip the border arithmetic
@@ -262,8 +288,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       const Lane l = lane_of(fresh_tid());
 #pragma unroll
       for (int k = 0; k < MAIN; ++k)
-        v[k] = s[slot_src(t.x0, y0, interior, 2 * r + ROWS_PER_PASS * k + l.m_row, r + l.m_col)];
-      if (l.s_on) v[MAIN] = s[slot_src(t.x0, y0, interior, 2 * r + l.s_row, l.s_lx)];
+        v[k] = pixel_at(s, slot_src(t.x0, y0, interior, 2 * r + ROWS_PER_PASS * k + l.m_row, r + l.m_col));
+      if (l.s_on) v[MAIN] = pixel_at(s, slot_src(t.x0, y0, interior, 2 * r + l.s_row, l.s_lx));
 #endif
     }
   };
@@ -375,6 +401,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       }
       USM_SYNC();
 
+      // the image covers the whole tile and every pair's slot is 4-byte aligned: stores without per-lane tests
+      const bool inside = x0 + TW <= W && y0 + TH <= H && (W & 1) == 0;
       // ---- phase 3: column pass, mask logic, Lab -> sRGB, encode, store ----
       // one pixel pair at a time: everything after the blur
       auto pair_out = [&](int ly, int px, v2f blur) {
@@ -445,7 +473,10 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
 #ifdef SS_ABL_NO_STORE
         asm volatile("" ::"v"(o.r.x), "v"(o.r.y), "v"(o.g.x), "v"(o.g.y), "v"(o.b.x), "v"(o.b.y));
 #else
-        usm_store_pair<OUT, PLAIN>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
+        if (inside)
+          usm_store_pair_inside<OUT, PLAIN>(d, W, y0 + ly, x0 + px, px_lo(o), px_hi(o));
+        else
+          usm_store_pair<OUT, PLAIN>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
 #endif
       };
       if constexpr (MFMA) {
@@ -639,7 +670,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       if (first) {  // upper halo rows [0, 2r): only a first tile has to compute them
         for (int idx = tid; idx < 2 * r * PWv; idx += NT) {
           const int ly = idx / PWv, lx = idx - ly * PWv;
-          slot_compute(s[slot_src(x0, y0, interior, ly, lx)], ly, lx);
+          slot_compute(pixel_at(s, slot_src(x0, y0, interior, ly, lx)), ly, lx);
         }
       }
       // the pixels of the last r new rows belong to the NEXT tile's first r plane rows: they wait in
@@ -673,7 +704,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       } else {
         for (int idx = tid; idx < n_new; idx += NT) {
           const int ly = idx / PWv, lx = idx - ly * PWv;
-          slot_compute(s[slot_src(x0, y0, interior, ly + 2 * r, lx)], ly + 2 * r, lx);
+          slot_compute(pixel_at(s, slot_src(x0, y0, interior, ly + 2 * r, lx)), ly + 2 * r, lx);
         }
       }
       if (last_of_seg && tid == 0) next_seg = drawn;
