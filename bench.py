@@ -13,9 +13,14 @@ statistics, [RCCL all-gather when N > 1], multipliers) -> ColorChecker CCM (Cheu
 
 Rank 0 prints ONE JSON line.  `value` is whole-job MP/s (all ranks) with inputs resident in HBM;
 `roofline` prices the fused unsharp-mask kernel against the 8 TB/s HBM peak using its ALGORITHMIC
-bytes (12 B/px float32 in + 6 B/px uint16 out = 18 B/px); `cpu_baseline` times the numpy
-restatement of the reference's path (oracle/, a port: the reference itself cannot be imported
-on the GPU box) on one 24 MP image with one thread.
+bytes (12 B/px float32 in + 6 B/px uint16 out = 18 B/px) and the kernel time measured here with
+events on the library's stream.  The kernel is bound by the vector ALU, not by HBM: `bound` says
+so, and `valu_frac` prices the instruction count of the committed counter passes (the file is
+named with its SHA-256; tools/pmc_bench.sh makes it from this very command) at this run's pixel
+rate against one wave-instruction per SIMD per 4 cycles.  `others` times the kernels of the other
+single-GPU configurations in the same process; `cpu_baseline` times the numpy restatement of the
+reference's path (oracle/, a port: the reference itself cannot be imported on the GPU box) on
+three 24 MP images with one thread, then on 4 and on all (at most 16) threads.
 """
 
 from __future__ import annotations
@@ -36,11 +41,22 @@ THUMB_H, THUMB_W = 341, 512
 SHADOW_LIMIT, HIGHLIGHT_LIMIT = 0.06, 0.96
 HBM_PEAK_GBS = 8000.0
 ALGO_BYTES_PER_PX = 18.0  # 12 in (float32 RGB) + 6 out (uint16 RGB)
-# HBM traffic of the unsharp-mask kernel per pixel, from the rocprofv3 PMC passes kept under profiles/
-# (FETCH_SIZE doubled as gfx950 needs, calibrated on the pointwise kernel's known 12 B/px; WRITE_SIZE as read):
-# 12.68 B/px fetched (what is left of the tile halos after the per-XCD deal of segments; 14.85 before it) +
-# 6.20 B/px written (streaming stores).  It cannot be collected inside this process; re-measure it when the kernel's tiling changes.
-MEASURED_TRAFFIC_BYTES_PER_PX = 18.88
+# Counter-derived figures of the dominant kernel (VALU instructions and HBM bytes per pixel, clock) cannot be collected
+# inside this process; they come from the rocprofv3 PMC passes summarised in this file (made by tools/pmc_summary.py
+# from the passes' CSVs, committed beside them), which the bench line names together with its SHA-256.  No file, no
+# figure: nothing is hard-coded.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_usm_pmc.json")
+N_SIMD = 1024
+
+
+def pmc_summary():
+    import hashlib
+
+    try:
+        raw = open(PMC_SUMMARY, "rb").read()
+        return json.loads(raw), hashlib.sha256(raw).hexdigest()
+    except (OSError, ValueError):
+        return None, None
 
 
 def synthetic_swatches():
@@ -97,6 +113,25 @@ def cpu_baseline(amount, n_images=3):
     else:
         run_threads()
     dt_mt = time.perf_counter() - t1
+    # every core this process may use (16 on the one-GPU box; os.cpu_count() there shows the whole machine)
+    try:
+        n_all = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n_all = os.cpu_count() or 1
+    n_all = max(1, min(n_all, 16))
+    every = [more[i % len(more)] for i in range(n_all)]
+
+    def run_all_cores():
+        with ThreadPoolExecutor(n_all) as pool:
+            list(pool.map(lambda im: oc.config2(im, M_T, M_R, 1.1, amount, 2.0, 0.0), every))
+
+    t2 = time.perf_counter()
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            run_all_cores()
+    else:
+        run_all_cores()
+    dt_all = time.perf_counter() - t2
     return {
         "value": round(n_images * H * W / 1e6 / dt, 3), "unit": "MP/s", "cores": 1, "kind": "port",
         "sample": f"{n_images} of the 64 images of {H}x{W} (24 MP) through oracle.chain.config2 (float64 numpy restatement "
@@ -104,6 +139,9 @@ def cpu_baseline(amount, n_images=3):
         "threads4": {"value": round(len(more) * H * W / 1e6 / dt_mt, 3), "unit": "MP/s", "cores": threads,
                      "sample": f"{len(more)} images on {threads} Python threads (the reference's default worker count), "
                                f"{dt_mt:.1f} s"},
+        "threads_all": {"value": round(n_all * H * W / 1e6 / dt_all, 3), "unit": "MP/s", "cores": n_all,
+                        "sample": f"{n_all} images on {n_all} Python threads (every core this process may use, at most 16), "
+                                  f"{dt_all:.1f} s"},
     }
 
 
@@ -111,11 +149,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # (the GPU's clocks need a few 10 ms launches to settle: the first two steps run 5-15 % slower)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: about 2 s of GPU time)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--amount", type=float, default=1.0, help="unsharp-mask amount (BASELINE: 1.0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the kernel timings of the other BASELINE configurations")
     ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
                     help="config2 = BASELINE.json configs[1] (default, the headline); config5 = the dataset-normalisation "
                          "scaling case: thumbnail statistics -> all-gather -> multipliers -> CCM + gain + sRGB, float32 "
@@ -214,6 +253,63 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def others():
+        """Kernel timings of the other BASELINE configurations in this process (HIP events on the library's stream,
+        inputs resident): configs[0] (pointwise CCM), configs[2] (negative mode with its percentile search) and
+        configs[3] (45 MP, root-polynomial CCM + shadows/highlights), each against its own algorithmic bytes."""
+        from scanspaceimageprocessor_amd import _lib
+
+        def timed(fn, reps=10, warm=3):
+            for _ in range(warm):
+                fn()
+            ctx.sync()
+            ts = []
+            for _ in range(reps):
+                ctx.timer_start()
+                fn()
+                ts.append(ctx.timer_stop())
+            return float(np.mean(ts))
+
+        def entry(config, kernel, bytes_px, n_px, ms):
+            gbs = bytes_px * n_px / (ms * 1e-3) / 1e9
+            return {"config": config, "kernel": kernel, "kernel_ms": round(ms, 4), "MP_per_s": round(n_px / 1e6 / (ms * 1e-3), 1),
+                    "algorithmic_bytes_per_px": bytes_px, "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        res = []
+        flat = images.view(-1)
+        out32 = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        n_px = float(B) * H * W
+        d1 = make_desc(H, W, B, ccm=ccm, gains=[1.0], out="f32_srgb")
+        res.append(entry(f"configs[0] x{B}: CCM 3 terms + clip + sRGB, float32 out", "chain_kernel<CCM_LIN3, F32_SRGB>", 24.0, n_px,
+                         timed(lambda: ctx.chain_run(d1, images.data_ptr(), out32.data_ptr()))))
+        # configs[3]: 45 MP images in the same storage, fresh linear data
+        H4, W4 = 5504, 8256
+        B4 = min(16, int(flat.numel() // (H4 * W4 * 3)))
+        img4 = flat[: B4 * H4 * W4 * 3].view(B4, H4, W4, 3)
+        for i in range(B4):
+            img4[i].uniform_(0.0, 1.0).pow_(2.2).mul_(0.9)
+        out4 = out32.view(-1)[: B4 * H4 * W4 * 3].view(B4, H4, W4, 3)
+        ccm4 = matrix_colour_correction(M_T, M_R, method="Finlayson 2015", degree=2)
+        d4 = make_desc(H4, W4, B4, ccm=ccm4, gains=[1.0], sh=(0.5, -0.5, 7.0), final_clip=True, out="f32")
+        res.append(entry(f"configs[3] x{B4}: 45 MP, root-polynomial CCM degree 2 + clip + Lab shadows/highlights, float32 out",
+                         "chain_kernel<CCM_SMALL, S/H, F32_LINEAR>", 24.0, float(B4) * H4 * W4,
+                         timed(lambda: ctx.chain_run(d4, img4.data_ptr(), out4.data_ptr()))))
+        # configs[2]: colour-negative look of fresh data, percentile search + inversion + CCM
+        orange = torch.tensor([1.0, 0.75, 0.55], device=dev)
+        for i in range(B):
+            images[i].uniform_(0.0, 1.0).pow_(2.2).mul_(0.9).mul_(-1.0).add_(1.0).mul_(0.8).mul_(orange).add_(0.08)
+        params = torch.empty((B, _lib.SS_NEG_PARAM_STRIDE), dtype=torch.float32, device=dev)
+        d3 = make_desc(H, W, B, neg=True, neg_params_dev=params.data_ptr(), ccm=ccm, out="f32")
+        torch.cuda.synchronize(dev)
+
+        def run3():
+            ctx.negative_params(images.data_ptr(), H, W, B, 0.005, 0.995, True, params.data_ptr())
+            ctx.chain_run(d3, images.data_ptr(), out32.data_ptr())
+
+        res.append(entry(f"configs[2] x{B}: percentiles (0.5 / 99.5) + inversion + CCM 3 terms, float32 out",
+                         "pct_* + chain_kernel<CCM_LIN3, F32_LINEAR>", 24.15, n_px, timed(run3)))
+        return res
+
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if os.environ.get("SS_BENCH_VERBOSE"):
         print("kernel ms per step:", [round(a.elapsed_time(b), 3) for a, b in ev], file=sys.stderr)
@@ -248,21 +344,34 @@ def main():
                 "images_per_gpu": B, "height": H, "width": W, "parallelism": f"image-sharded x{world}",
                 "collective": "all_gather of per-image brightness (RCCL)" if world > 1 else "none",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "chain_kernel<CCM_LIN3, no S/H, F32_SRGB>" if config5 else "usm_kernel<6, CCM_LIN3, U16_SRGB, plain>",
-                "achieved": round(achieved_gbs, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                "traffic": round((24.0 if config5 else MEASURED_TRAFFIC_BYTES_PER_PX) * px_per_launch),
-                "traffic_note": ("bytes per launch = 24.0 B/px" if config5 else "bytes per launch = 18.88 B/px")
-                                + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) x px_per_launch",
-                "limiter": ("HBM streaming" if config5 else
-                            "vector ALU, not HBM: 201 VALU instructions per pixel (25 of them log2/exp2), VALU busy 93.5 % "
-                            "of the kernel's cycles (rocprofv3 SQ counters, profiles/r01_usm_pmc.md)"),
-                "algorithmic_bytes_per_px": algo_bytes,
-                "px_per_launch": px_per_launch, "kernel_ms": round(kernel_ms, 4),
-            },
         }
+        pmc, pmc_sha = (None, None) if config5 else pmc_summary()
+        px_per_s = px_per_launch / (kernel_ms * 1e-3)
+        roof = {
+            # what limits the kernel: the pointwise chain streams (HBM); the tile kernel is bound by the vector ALU
+            "bound": "hbm" if config5 else "valu",
+            "kernel": "chain_kernel<CCM_LIN3, no S/H, F32_SRGB>" if config5 else "usm_kernel<6, CCM_LIN3, U16_SRGB, plain>",
+            # the HBM roofline all the same: algorithmic bytes per launch / measured kernel time against 8 TB/s
+            "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_px": algo_bytes, "px_per_launch": px_per_launch, "kernel_ms": round(kernel_ms, 4),
+            "traffic": None,
+        }
+        if pmc is not None:
+            clock_hz = pmc["clock_ghz"] * 1e9
+            roof.update({
+                # HBM bytes per launch from the counter passes (FETCH_SIZE doubled as gfx950 needs + WRITE_SIZE)
+                "traffic": round((pmc["fetch_bytes_per_px"] + pmc["write_bytes_per_px"]) * px_per_launch),
+                # vector-ALU roofline: instructions issued per second against one wave-instruction per SIMD per 4
+                # cycles (transcendental ones take two such slots)
+                "valu_instructions_per_px": pmc["valu_per_px"], "valu_trans_per_px": pmc["trans_per_px"],
+                "valu_frac": round((pmc["valu_per_px"] + pmc["trans_per_px"]) * px_per_s / (N_SIMD * clock_hz / 4 * 64), 4),
+                "valu_busy_profiled": pmc["valu_busy"], "clock_ghz_profiled": pmc["clock_ghz"],
+                "pmc_file": os.path.relpath(PMC_SUMMARY, ROOT), "pmc_sha256": pmc_sha,
+            })
+        line["roofline"] = roof
+        if world == 1 and not args.no_others and not config5:
+            line["others"] = others()
         if world == 1 and not args.no_cpu_baseline and not config5:
             line["cpu_baseline"] = cpu_baseline(args.amount)
         print(json.dumps(line), flush=True)

@@ -24,6 +24,9 @@
 #define I_FMACL(n) "v_fma_f32 %" #n ", %" #n ", %8, %9 clamp\n"
 #define I_PKMUL(n) "v_pk_mul_f32 %" #n ", %" #n ", %10\n"
 #define I_LOG(n) "v_log_f32 %" #n ", %" #n "\n"
+#define I_SEL32(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
+#define I_SEL64(n) "v_cmp_lt_f32_e64 s[20:21], %" #n ", %8\n v_cndmask_b32_e64 %" #n ", %" #n ", %9, s[20:21]\n"
+#define I_SELFAR(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n v_mul_f32 %" #n ", %" #n ", %8\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
       if (MODE == 4) asm volatile(REP8(I_MED) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
 #define ONE(M, I) if (MODE == M) asm volatile(REP8(I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc", "s20", "s21");
       ONE(6, I_MIN) ONE(7, I_MUL) ONE(8, I_ADD) ONE(9, I_CMP) ONE(10, I_CND64) ONE(11, I_MOV) ONE(12, I_IADD) ONE(13, I_CVT)
-      ONE(14, I_AND) ONE(15, I_FMAC) ONE(16, I_MAXC) ONE(17, I_FMACL) ONE(19, I_LOG)
+      ONE(14, I_AND) ONE(15, I_FMAC) ONE(16, I_MAXC) ONE(17, I_FMACL) ONE(19, I_LOG) ONE(20, I_SEL32) ONE(21, I_SEL64) ONE(22, I_SELFAR)
       if (MODE == 18) asm volatile(REP8(I_PKMUL) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(a), "v"(b), "v"(a2), "v"(b2));
       if (MODE == 5) {  // the kernel's mix: 2 plain, 1 packed, 1 transcendental in 8
         asm volatile(I_FMA(0) I_PK(1) I_FMA(2) I_EXP(3) I_FMA(4) I_PK(5) I_MED(6) I_PK(7)
@@ -91,5 +94,6 @@ int main() {
   run<8>("v_add_f32", out, w); run<9>("v_cmp_lt_f32", out, w); run<11>("v_mov_b32", out, w); run<12>("v_add_u32", out, w);
   run<13>("v_cvt_u32_f32", out, w); run<14>("v_and_b32", out, w); run<15>("v_fmac_f32", out, w); run<16>("v_max clamp", out, w);
   run<17>("v_fma clamp", out, w); run<18>("v_pk_mul_f32", out, w); run<19>("v_log_f32", out, w);
+  run<20>("cmp+cnd vcc (x2 instr)", out, w); run<21>("cmp+cnd sgpr (x2)", out, w); run<22>("cmp,mul,cnd vcc (x3)", out, w);
   return 0;
 }
