@@ -156,6 +156,15 @@ const char* ss_version(void);
  * apply_all_adjustments (editingTools.py:823-909) and its callees. */
 int ss_chain_run(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev);
 
+/* One pass, two outputs: ss_chain_run, and from the same registers a second, 8-bit image of the corrected pixels:
+ * dst2_dev [batch][H][W][3] uint8 in out_kind2 = SS_OUT_U8_LINEAR (the worker's preview,
+ * np.clip(corrected, 0, 1) * 255 -> uint8, imageProcessorWorker.py:922: derived from the array that is also encoded
+ * and written, imageProcessorWorker.py:907-921) or SS_OUT_U8_SRGB.  Both outputs are bit for bit what two
+ * ss_chain_run calls with the two output kinds give; the second costs 3 B/px of stores instead of a second pass.
+ * dst2_dev must not overlap src_dev or dst_dev. */
+int ss_chain_run2(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev, int out_kind2,
+                  void* dst2_dev);
+
 /* Options of the host-buffer entry point. */
 typedef struct ss_host_opts {
   /* neg_auto != 0 with desc->neg_enabled and desc->neg_params_dev == NULL: compute the percentiles on

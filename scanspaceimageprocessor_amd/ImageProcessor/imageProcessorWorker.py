@@ -282,23 +282,28 @@ class ImageCorrectionWorker:
             # (a chain with no stage) writes into `src`, whose contents are no longer needed.
             ctx.chain_run(make_desc(h, w, 1, out="f32", **kw), src, dst)
             self._apply_masking_device(ctx, dst, h, w)
-            ctx.chain_run(make_desc(h, w, 1, out=kind), dst, src)
+            # The preview is made from the array that is encoded (imageProcessorWorker.py:907-922): both outputs
+            # of one pass over it.
+            if np.dtype(_lib.OUT_DTYPES[kind]) == np.uint8:
+                ctx.chain_run(make_desc(h, w, 1, out=kind), dst, src)
+                ctx.download(encoded, src)
+                return encoded, encoded
+            pre = ctx.workspace("worker.preview", h * w * 3)
+            ctx.chain_run2(make_desc(h, w, 1, out=kind), dst, src, _lib.SS_OUT_U8_LINEAR, pre)
             ctx.download(encoded, src)
-            if encoded.dtype == np.uint8:
-                preview = encoded
-            else:
-                preview = host_array("worker.preview", np.uint8)
-                ctx.chain_run(make_desc(h, w, 1, out="u8_linear"), dst, src)
-                ctx.download(preview, src)
-            return encoded, preview
-        ctx.chain_run(make_desc(h, w, 1, out=kind, **kw), src, dst)
-        ctx.download(encoded, dst)
-        if encoded.dtype == np.uint8:
-            preview = encoded
-        else:
             preview = host_array("worker.preview", np.uint8)
-            ctx.chain_run(make_desc(h, w, 1, out="u8_linear", **kw), src, dst)
-            ctx.download(preview, dst)
+            ctx.download(preview, pre)
+            return encoded, preview
+        if np.dtype(_lib.OUT_DTYPES[kind]) == np.uint8:
+            ctx.chain_run(make_desc(h, w, 1, out=kind, **kw), src, dst)
+            ctx.download(encoded, dst)
+            return encoded, encoded
+        # one pass over the image, two outputs: the encoded image and the 8-bit linear preview of the same pixels
+        pre = ctx.workspace("worker.preview", h * w * 3)
+        ctx.chain_run2(make_desc(h, w, 1, out=kind, **kw), src, dst, _lib.SS_OUT_U8_LINEAR, pre)
+        ctx.download(encoded, dst)
+        preview = host_array("worker.preview", np.uint8)
+        ctx.download(preview, pre)
         return encoded, preview
 
     # ------------------------------------------------------------------ masking

@@ -93,6 +93,7 @@ SIGNATURES = {
     "ss_last_error": (C.c_char_p, [C.c_void_p]),
     "ss_version": (C.c_char_p, []),
     "ss_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
+    "ss_chain_run2": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ss_chain_run_static": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
     "ss_chain_requeued": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ss_chain_run_host": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p, C.POINTER(HostOpts)]),
@@ -312,6 +313,11 @@ class Context:
     # -- entry points on device pointers
     def chain_run(self, desc, src_dev, dst_dev):
         self.check(self.lib.ss_chain_run(self.handle, C.byref(desc), C.c_void_p(src_dev), C.c_void_p(dst_dev)))
+
+    def chain_run2(self, desc, src_dev, dst_dev, out_kind2, dst2_dev):
+        """``chain_run`` with a second, 8-bit output (``SS_OUT_U8_LINEAR`` or ``SS_OUT_U8_SRGB``) from the same pass."""
+        self.check(self.lib.ss_chain_run2(self.handle, C.byref(desc), C.c_void_p(src_dev), C.c_void_p(dst_dev),
+                                          int(out_kind2), C.c_void_p(dst2_dev)))
 
     def chain_run_static(self, desc, src_dev, dst_dev):
         """``chain_run`` without any allocation inside the call (work-queue counters in the library's static device

@@ -455,6 +455,8 @@ int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, cons
     B.ccm_kind = SS_CCM_NONE;
     B.ccm_terms = 0;
     if (B.gain0_dev) B.gain0_dev += first;
+    A.dst2 = nullptr;  // the second output is made where the first is
+    if (B.dst2) B.dst2 += (size_t)first * P.n_px * 3;
     rc = launch_chain_and_careful(c, A, n, SS_OUT_F32_LINEAR, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, S);
     if (rc) return rc;
     rc = launch_chain_and_careful(c, B, n, d->out_kind, (const float*)c->ws_stage,
@@ -562,13 +564,16 @@ int ss_ctx_sync(ss_ctx* c) {
 
 const char* ss_last_error(const ss_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
-int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev) {
+static int chain_run_two(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev, int out_kind2,
+                         void* dst2_dev) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!src_dev || !dst_dev) return fail(c, SS_ERR_INVALID, "src_dev and dst_dev must not be NULL");
   ChainParams P;
   rc = build_params(c, d, &P);
   if (rc) return rc;
+  P.dst2 = (unsigned char*)dst2_dev;
+  P.dst2_encoded = out_kind2 == SS_OUT_U8_SRGB ? 1 : 0;
   if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
     return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
   ChainScratch S{c->usm_ticket, RiskMap{nullptr, nullptr, nullptr}};
@@ -578,6 +583,21 @@ int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* 
   }
   if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3) return run_staged_usm(c, d, P, src_dev, dst_dev, S);
   return launch_chain_and_careful(c, P, d->batch, d->out_kind, src_dev, dst_dev, S);
+}
+
+int ss_chain_run(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev) {
+  return chain_run_two(c, d, src_dev, dst_dev, SS_OUT_U8_LINEAR, nullptr);
+}
+
+int ss_chain_run2(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev, int out_kind2, void* dst2_dev) {
+  if (!c) return fail(nullptr, SS_ERR_INVALID, "context is NULL");
+  if (!dst2_dev) return fail(c, SS_ERR_INVALID, "dst2_dev must not be NULL");
+  if (out_kind2 != SS_OUT_U8_LINEAR && out_kind2 != SS_OUT_U8_SRGB)
+    return fail(c, SS_ERR_INVALID, "the second output is 8-bit: out_kind2 must be SS_OUT_U8_LINEAR or SS_OUT_U8_SRGB, not %d",
+                out_kind2);
+  if (dst2_dev == dst_dev || dst2_dev == (const void*)src_dev)
+    return fail(c, SS_ERR_INVALID, "dst2_dev must not be src_dev or dst_dev");
+  return chain_run_two(c, d, src_dev, dst_dev, out_kind2, dst2_dev);
 }
 
 int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev, void* dst_dev) {
@@ -592,7 +612,7 @@ int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev,
   if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3)
     return fail(c, SS_ERR_UNSUPPORTED,
                 "an unsharp mask behind a %d-term colour correction needs a float32 staging image per image of the "
-                "batch, beyond the 256-byte static scratch of ss_chain_run_static: use ss_chain_run",
+                "batch, which the static scratch of ss_chain_run_static does not hold: use ss_chain_run",
                 P.ccm_terms);
   if (P.usm) {
     // the work queue's counters are 32-bit tickets over the segments of the whole batch

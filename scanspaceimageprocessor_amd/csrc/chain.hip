@@ -88,10 +88,18 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
 #pragma unroll
     for (int q = 0; q < 4; q += 2) {
       RiskT<v2f> risk{};
-      const Px2 o2 = finish<OUT, false, v2f>(
-          front<CCMC, SH, false, v2f>(pair_px(Px{in[q].x, in[q].y, in[q].z}, Px{in[q + 1].x, in[q + 1].y, in[q + 1].z}), P,
-                                      ip, M, SH ? &risk : nullptr),
-          P);
+      const Px2 f2 = front<CCMC, SH, false, v2f>(
+          pair_px(Px{in[q].x, in[q].y, in[q].z}, Px{in[q + 1].x, in[q + 1].y, in[q + 1].z}), P, ip, M, SH ? &risk : nullptr);
+      {  // the second output, when the call has one (a scalar branch on a kernel argument)
+        const ChainParams& Pk = kernarg_params();
+        if (Pk.dst2 != nullptr) {
+          const uint32_t p0 = base * G + q * 256 + threadIdx.x, p1 = p0 + 256;
+          const bool clip = Pk.final_clip != 0, enc = Pk.dst2_encoded != 0;
+          if (p0 < n) store_second(Pk.dst2, (size_t)img * n + p0, px_lo(f2), clip, enc);
+          if (p1 < n) store_second(Pk.dst2, (size_t)img * n + p1, px_hi(f2), clip, enc);
+        }
+      }
+      const Px2 o2 = finish<OUT, false, v2f>(f2, P);
       res[q] = px_lo(o2);
       res[q + 1] = px_hi(o2);
       if constexpr (SH && RiskCfg<OUT>::ENABLED) {
@@ -162,7 +170,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
       const F3 v = s[px];
       const ChainParams& P = params_now();
       Px o = finish<OUT, false, float>(front<CCMC, SH, false, float>(Px{v.x, v.y, v.z}, P, ip, M), P);
-      // (the main loop has already recorded these pixels: it evaluates every pixel, it just does not store them)
+      // (the main loop has already recorded these pixels and stored their second output: it evaluates every pixel,
+      // it just does not store the first output of these)
       store_one<OUT>(d, px, o);
     }
   }

@@ -61,6 +61,10 @@ struct ChainParams {
   unsigned long long* risk_bits;
   uint32_t* risk_any;
   uint32_t* risk_count;
+  // Second output of the same pass: 3 bytes per pixel, [batch][H][W][3], made from the pixel as it stands before
+  // the output encoding (null = none).  Set by the launcher, read where the kernels store (through kernarg_params).
+  unsigned char* dst2;
+  int dst2_encoded;  // 1 = SS_OUT_U8_SRGB, 0 = SS_OUT_U8_LINEAR
 };
 
 // The kernel's parameter block as its kernel-argument segment holds it (the block is every kernel's FIRST argument),
@@ -868,6 +872,17 @@ __device__ __forceinline__ uint32_t quant8(float x) { return (uint32_t)clampf(x 
 // the same for x known to lie in [0, 1]: the product cannot leave the range, the conversion truncates
 __device__ __forceinline__ uint32_t quant16_unit(float x) { return (uint32_t)(x * 65535.0f); }
 __device__ __forceinline__ uint32_t quant8_unit(float x) { return (uint32_t)(x * 255.0f); }
+
+// The second, 8-bit output of one pixel (ChainParams::dst2) from its value after stage 6: exactly what the chain
+// with that output kind would store.  `px`: pixel index in the batch.
+__device__ __forceinline__ void store_second(unsigned char* dst2, size_t px, Px v, bool clip, bool encoded) {
+  if (clip) v = Px{clamp01(v.r), clamp01(v.g), clamp01(v.b)};
+  if (encoded) v = Px{srgb_encode(v.r), srgb_encode(v.g), srgb_encode(v.b)};
+  unsigned char* d = dst2 + px * 3;
+  d[0] = (unsigned char)quant8(v.r);
+  d[1] = (unsigned char)quant8(v.g);
+  d[2] = (unsigned char)quant8(v.b);
+}
 
 // lane granularity per output kind: G adjacent pixels per lane make a 12-byte store
 template <int OUT>

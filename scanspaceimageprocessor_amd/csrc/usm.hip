@@ -402,7 +402,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       USM_SYNC();
 
       // the image covers the whole tile and every pair's slot is 4-byte aligned: stores without per-lane tests
-      const bool inside = x0 + TW <= W && y0 + TH <= H && (W & 1) == 0;
+      // (a call with a second output takes the general path throughout: one scalar flag decides both)
+      const bool inside = x0 + TW <= W && y0 + TH <= H && (W & 1) == 0 && kernarg_params().dst2 == nullptr;
       // ---- phase 3: column pass, mask logic, Lab -> sRGB, encode, store ----
       // one pixel pair at a time: everything after the blur
       auto pair_out = [&](int ly, int px, v2f blur) {
@@ -432,6 +433,16 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
           }
           o = usm_on_rgb<PLAIN, v2f>(lin, Ln, blur, P, &risk);
           risk.mx = risk.mx + carried;
+        }
+        if (!inside) {  // the second output, when the call has one
+          const ChainParams& Pk = kernarg_params();
+          if (Pk.dst2 != nullptr) {
+            const int Wk = Pk.width, gy = y0 + ly, gx = x0 + px;
+            const size_t at = ((size_t)cur.img * Pk.height + gy) * Wk + gx;
+            const bool enc = Pk.dst2_encoded != 0;
+            if (gy < Pk.height && gx < Wk) store_second(Pk.dst2, at, px_lo(o), false, enc);
+            if (gy < Pk.height && gx + 1 < Wk) store_second(Pk.dst2, at + 1, px_hi(o), false, enc);
+          }
         }
         // the sharpened pixel is in [0,1]; the LAB branch has no final clip: either way the clip stage is a no-op here
         o = finish<OUT, true, v2f>(o, P);
