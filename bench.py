@@ -155,6 +155,10 @@ def main():
     ap.add_argument("--amount", type=float, default=1.0, help="unsharp-mask amount (BASELINE: 1.0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the kernel timings of the other BASELINE configurations")
+    ap.add_argument("--collective", choices=("torch", "abi"), default="torch",
+                    help="N > 1: the all-gather through torch.distributed (default) or through the library's own "
+                         "ss_allgather_stats (RCCL resolved by the library; torch.distributed only carries the "
+                         "communicator's identifier to the ranks)")
     ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
                     help="config2 = BASELINE.json configs[1] (default, the headline); config5 = the dataset-normalisation "
                          "scaling case: thumbnail statistics -> all-gather -> multipliers -> CCM + gain + sRGB, float32 "
@@ -214,7 +218,15 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
-    norm = ExposureNormaliser(ctx, n_total, rank, world, SHADOW_LIMIT, HIGHLIGHT_LIMIT)
+    gather = None
+    if world > 1 and args.collective == "abi":
+        from scanspaceimageprocessor_amd import _lib
+        from scanspaceimageprocessor_amd.dataset import AbiGather
+
+        ident = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        gather = AbiGather(ctx, ctx.comm_create(ident[0], rank, world), rank, world)
+    norm = ExposureNormaliser(ctx, n_total, rank, world, SHADOW_LIMIT, HIGHLIGHT_LIMIT, gather=gather)
     gains = norm.gains
 
     M_T, M_R = synthetic_swatches()
@@ -342,7 +354,7 @@ def main():
                              f"mask (radius 2, amount {args.amount:g}) + sRGB encode + 16-bit quantise "
                              "(BASELINE.json configs[1])"),
                 "images_per_gpu": B, "height": H, "width": W, "parallelism": f"image-sharded x{world}",
-                "collective": "all_gather of per-image brightness (RCCL)" if world > 1 else "none",
+                "collective": (f"all_gather of per-image brightness (RCCL, through {args.collective})") if world > 1 else "none",
             },
         }
         pmc, pmc_sha = (None, None) if config5 else pmc_summary()

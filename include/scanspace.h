@@ -257,6 +257,34 @@ int ss_exposure_stats(ss_ctx* ctx, const float* thumbs_dev, int32_t height, int3
 int ss_exposure_multipliers(ss_ctx* ctx, const float* brightness_dev, int32_t n, int32_t ref_index,
                             int32_t first, int32_t count, float* mult_dev);
 
+/* ---- multi-GPU: the one exchange step of the dataset exposure normalisation ------------------------------------ */
+
+/* One process per GPU, each with the contiguous range of images ss_shard_range gives it (the reference chunks its
+ * image list over worker threads the same way, image_space.py:3423-3425).  Every rank needs the brightness of ALL
+ * images to form the reference value (image_space.py:4368-4394): ss_exposure_stats on the local thumbnails ->
+ * ss_allgather_stats -> ss_exposure_multipliers for the local range.  The collective is RCCL's, resolved at run
+ * time (the RCCL already loaded in the process, else librccl.so.1; SS_RCCL_LIB names another): hosts that never call
+ * these functions need no RCCL. */
+
+/* first / count of rank's contiguous, balanced share of n_items (the first n_items % world ranks hold one more). */
+int ss_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* first, int64_t* count);
+
+#define SS_COMM_ID_BYTES 128
+/* A fresh identifier for a communicator (ncclGetUniqueId): call on one rank, hand the bytes to every rank by any
+ * means the host has (a file, a socket, MPI), then every rank calls ss_comm_create with it. */
+int ss_comm_unique_id(char id[SS_COMM_ID_BYTES]);
+/* Collective over all `world` ranks: the communicator (an ncclComm_t) of this rank on the context's GPU. */
+int ss_comm_create(ss_ctx* ctx, const char id[SS_COMM_ID_BYTES], int32_t rank, int32_t world, void** comm);
+int ss_comm_destroy(ss_ctx* ctx, void* comm);
+
+/* Brightness of all n_images in image order on every rank: local_dev holds this rank's ss_shard_range(n_images, rank,
+ * world) values, all_dev receives n_images values (all_dev may not overlap local_dev).  `comm`: an ncclComm_t of
+ * `world` ranks in which this process is `rank` - from ss_comm_create, or the host's own communicator when it was
+ * made by the same RCCL library.  Even shards go out as one all-gather, uneven ones as one group of broadcasts;
+ * 4 bytes per image, latency-bound.  Queued on the context's stream behind ss_exposure_stats (asynchronous). */
+int ss_allgather_stats(ss_ctx* ctx, void* comm, int32_t rank, int32_t world, int64_t n_images, const float* local_dev,
+                       float* all_dev);
+
 /* ---- 16-bit RAW decode output -> float32 ------------------------------------------------------ */
 
 /* load_image's `np.array(rgb, dtype=np.float32) / 65535.0` (imageProcessorWorker.py:313; imageLoader.py:92) on

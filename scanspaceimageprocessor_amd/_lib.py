@@ -93,6 +93,11 @@ SIGNATURES = {
     "ss_last_error": (C.c_char_p, [C.c_void_p]),
     "ss_version": (C.c_char_p, []),
     "ss_chain_run": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
+    "ss_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ss_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ss_comm_create": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ss_comm_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_allgather_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "ss_chain_run2": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ss_chain_run_static": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_void_p]),
     "ss_chain_requeued": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -319,6 +324,22 @@ class Context:
         self.check(self.lib.ss_chain_run2(self.handle, C.byref(desc), C.c_void_p(src_dev), C.c_void_p(dst_dev),
                                           int(out_kind2), C.c_void_p(dst2_dev)))
 
+    # -- multi-GPU: communicator and the one collective
+    def comm_create(self, comm_id, rank, world):
+        """This rank's communicator (an ``ncclComm_t`` as an integer) from the bytes of ``comm_unique_id()``.
+        Collective over all ranks."""
+        comm = C.c_void_p()
+        self.check(self.lib.ss_comm_create(self.handle, bytes(comm_id), int(rank), int(world), C.byref(comm)))
+        return comm.value
+
+    def comm_destroy(self, comm):
+        self.check(self.lib.ss_comm_destroy(self.handle, C.c_void_p(comm)))
+
+    def allgather_stats(self, comm, rank, world, n_images, local_dev, all_dev):
+        """Brightness of all ``n_images`` in image order into ``all_dev`` on every rank (asynchronous)."""
+        self.check(self.lib.ss_allgather_stats(self.handle, C.c_void_p(comm), int(rank), int(world), int(n_images),
+                                               C.c_void_p(local_dev), C.c_void_p(all_dev)))
+
     def chain_run_static(self, desc, src_dev, dst_dev):
         """``chain_run`` without any allocation inside the call (work-queue counters in the library's static device
         scratch): for callers under graph capture.  Calls on one GPU must not overlap."""
@@ -425,6 +446,25 @@ def percentile_rank(n, fraction, legacy_numpy=True):
     if rc != SS_OK:
         raise ScanSpaceError(rc, "invalid percentile arguments")
     return lo.value, hi.value, g.value
+
+
+def shard_range(n_items, rank, world):
+    """Host-only: ``(first, count)`` of ``ss_shard_range``."""
+    first, count = C.c_int64(), C.c_int64()
+    rc = load_library().ss_shard_range(int(n_items), int(rank), int(world), C.byref(first), C.byref(count))
+    if rc != SS_OK:
+        raise ValueError(f"bad shard request: n={n_items} rank={rank} world={world}")
+    return first.value, count.value
+
+
+def comm_unique_id():
+    """128 bytes that identify a new communicator: make them on one rank, give them to every rank."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.ss_comm_unique_id(buf)
+    if rc != SS_OK:
+        raise ScanSpaceError(rc, lib.ss_last_error(None).decode())
+    return buf.raw
 
 
 def negative_sample_step(height, width):

@@ -1,6 +1,7 @@
 // C ABI of libscanspace_hip.so (declared in include/scanspace.h): context management, descriptor
 // validation, host-side parameter derivation, workspace and pinned staging.
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -10,6 +11,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+
+#include <rccl/rccl.h>  // types and signatures only: the library is resolved at run time
 
 #include "ss_internal.h"
 
@@ -1033,6 +1036,152 @@ int ss_chain_run_host(ss_ctx* c, const ss_chain_desc* d, const float* src_host, 
   rc = ss_chain_run(c, &dd, (const float*)c->host_src, c->host_dst);
   if (rc) return rc;
   return copy_d2h(c, dst_host, c->host_dst, out_bytes);
+}
+
+}  // extern "C"
+
+// ---- multi-GPU ---------------------------------------------------------------------------------------------------
+
+namespace {
+
+// RCCL's entry points, looked up once: first an RCCL that the process has loaded already (a host that made its own
+// communicator must meet the same library here), then the system's.
+struct Rccl {
+  void* handle = nullptr;
+  std::string why;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclBroadcast) broadcast = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+const Rccl& rccl() {
+  static const Rccl lib = [] {
+    Rccl r;
+    const char* names[4] = {getenv("SS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int pass = 0; pass < 2 && !r.handle; ++pass)
+      for (const char* n : names)
+        if (n && n[0] && !r.handle) r.handle = dlopen(n, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_LOCAL));
+    if (!r.handle) {
+      const char* e = dlerror();
+      r.why = std::string("RCCL could not be loaded (librccl.so.1; SS_RCCL_LIB names another): ") + (e ? e : "not found");
+      return r;
+    }
+    auto sym = [&](const char* name) -> void* {
+      void* p = dlsym(r.handle, name);
+      if (!p && r.why.empty()) r.why = std::string("RCCL lacks ") + name;
+      return p;
+    };
+    r.get_unique_id = (decltype(r.get_unique_id))sym("ncclGetUniqueId");
+    r.comm_init_rank = (decltype(r.comm_init_rank))sym("ncclCommInitRank");
+    r.comm_destroy = (decltype(r.comm_destroy))sym("ncclCommDestroy");
+    r.all_gather = (decltype(r.all_gather))sym("ncclAllGather");
+    r.broadcast = (decltype(r.broadcast))sym("ncclBroadcast");
+    r.group_start = (decltype(r.group_start))sym("ncclGroupStart");
+    r.group_end = (decltype(r.group_end))sym("ncclGroupEnd");
+    r.error_string = (decltype(r.error_string))sym("ncclGetErrorString");
+    return r;
+  }();
+  return lib;
+}
+
+#define SS_RCCL(c, R, call)                                                                                   \
+  do {                                                                                                        \
+    ncclResult_t r_ = (call);                                                                                 \
+    if (r_ != ncclSuccess) return fail((c), SS_ERR_HIP, "%s failed: %s", #call, (R).error_string(r_));        \
+  } while (0)
+
+void shard_of(int64_t n, int rank, int world, int64_t* first, int64_t* count) {
+  const int64_t base = n / world, extra = n % world;
+  *first = rank * base + (rank < extra ? rank : extra);
+  *count = base + (rank < extra ? 1 : 0);
+}
+
+}  // namespace
+
+static_assert(SS_COMM_ID_BYTES == sizeof(ncclUniqueId), "the identifier is RCCL's ncclUniqueId");
+
+extern "C" {
+
+int ss_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* first, int64_t* count) {
+  if (!first || !count || world < 1 || rank < 0 || rank >= world || n_items < 0) return SS_ERR_INVALID;
+  shard_of(n_items, rank, world, first, count);
+  return SS_OK;
+}
+
+int ss_comm_unique_id(char id[SS_COMM_ID_BYTES]) {
+  if (!id) return fail(nullptr, SS_ERR_INVALID, "id is NULL");
+  const Rccl& R = rccl();
+  if (!R.why.empty()) return fail(nullptr, SS_ERR_UNSUPPORTED, "%s", R.why.c_str());
+  ncclUniqueId u;
+  SS_RCCL(nullptr, R, R.get_unique_id(&u));
+  memcpy(id, &u, sizeof u);
+  return SS_OK;
+}
+
+int ss_comm_create(ss_ctx* c, const char id[SS_COMM_ID_BYTES], int32_t rank, int32_t world, void** comm) {
+  int rc = check_ctx(c);  // (makes the context's GPU current: the communicator binds to it)
+  if (rc) return rc;
+  if (!id || !comm) return fail(c, SS_ERR_INVALID, "id and comm must not be NULL");
+  *comm = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c, SS_ERR_INVALID, "rank %d of %d", rank, world);
+  const Rccl& R = rccl();
+  if (!R.why.empty()) return fail(c, SS_ERR_UNSUPPORTED, "%s", R.why.c_str());
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t k = nullptr;
+  SS_RCCL(c, R, R.comm_init_rank(&k, world, u, rank));
+  *comm = (void*)k;
+  return SS_OK;
+}
+
+int ss_comm_destroy(ss_ctx* c, void* comm) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!comm) return SS_OK;
+  const Rccl& R = rccl();
+  if (!R.why.empty()) return fail(c, SS_ERR_UNSUPPORTED, "%s", R.why.c_str());
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  SS_RCCL(c, R, R.comm_destroy((ncclComm_t)comm));
+  return SS_OK;
+}
+
+int ss_allgather_stats(ss_ctx* c, void* comm, int32_t rank, int32_t world, int64_t n_images, const float* local_dev,
+                       float* all_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!comm || !local_dev || !all_dev) return fail(c, SS_ERR_INVALID, "comm, local_dev and all_dev must not be NULL");
+  if (world < 1 || rank < 0 || rank >= world || n_images < 0)
+    return fail(c, SS_ERR_INVALID, "rank %d of %d, %lld images", rank, world, (long long)n_images);
+  if (n_images == 0) return SS_OK;
+  const Rccl& R = rccl();
+  if (!R.why.empty()) return fail(c, SS_ERR_UNSUPPORTED, "%s", R.why.c_str());
+  ncclComm_t k = (ncclComm_t)comm;
+  // (SS_ALLGATHER_BROADCASTS=1: the uneven form for even shards too, for tests)
+  const char* v = getenv("SS_ALLGATHER_BROADCASTS");
+  const bool always_v = v && v[0] == '1';
+  if (n_images % world == 0 && !always_v) {
+    SS_RCCL(c, R, R.all_gather(local_dev, all_dev, (size_t)(n_images / world), ncclFloat, k, c->stream));
+    return SS_OK;
+  }
+  // uneven shards: rank r's values go out from r, one group so that the launches fuse
+  SS_RCCL(c, R, R.group_start());
+  for (int r = 0; r < world; ++r) {
+    int64_t first, count;
+    shard_of(n_images, r, world, &first, &count);
+    if (count == 0) continue;
+    ncclResult_t e = R.broadcast(local_dev, all_dev + first, (size_t)count, ncclFloat, r, k, c->stream);
+    if (e != ncclSuccess) {
+      (void)R.group_end();
+      return fail(c, SS_ERR_HIP, "ncclBroadcast from rank %d failed: %s", r, R.error_string(e));
+    }
+  }
+  SS_RCCL(c, R, R.group_end());
+  return SS_OK;
 }
 
 int ss_timer_start(ss_ctx* c) {

@@ -54,6 +54,24 @@ def gather_brightness(local, n_images: int, group=None):
     return torch.cat(pieces)
 
 
+class AbiGather:
+    """``gather`` of an ``ExposureNormaliser`` through the C ABI alone (``ss_allgather_stats`` on the context's
+    stream, RCCL resolved by the library): what a host without torch.distributed calls.  ``comm`` comes from
+    ``ctx.comm_create(comm_id, rank, world)`` with the bytes of ``_lib.comm_unique_id()`` made on one rank."""
+
+    def __init__(self, ctx, comm, rank: int, world: int):
+        self.ctx, self.comm, self.rank, self.world = ctx, comm, rank, world
+        self.out = None
+
+    def __call__(self, local, n_images: int):
+        import torch
+
+        if self.out is None or self.out.numel() != n_images:
+            self.out = torch.empty((n_images,), dtype=torch.float32, device=local.device)
+        self.ctx.allgather_stats(self.comm, self.rank, self.world, n_images, local.data_ptr(), self.out.data_ptr())
+        return self.out
+
+
 class HipExposureOps:
     """The two device steps of dataset exposure normalisation on one context's GPU and stream
     (``ss_exposure_stats``, ``ss_exposure_multipliers``) over torch CUDA tensors."""

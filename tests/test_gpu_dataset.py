@@ -88,3 +88,70 @@ def test_calculate_average_exposure_over_mixed_thumbnail_shapes():
     np.testing.assert_allclose([got_c[p] for p in usable], want_c, rtol=1e-6)
     assert got_c[chart] == 1.0
     assert calculate_average_exposure({"/d/x.nef": None}, log=logs.append) == {}
+
+
+def test_all_gather_through_the_c_abi_alone(monkeypatch):
+    """ss_comm_unique_id -> ss_comm_create -> ss_exposure_stats -> ss_allgather_stats -> ss_exposure_multipliers:
+    the sequence of a host without torch.distributed, on a one-rank communicator (the box has one GPU, and RCCL
+    refuses two ranks on one device).  Both forms of the collective: one all-gather, and the group of broadcasts
+    that uneven shards use."""
+    from gpu_util import DeviceBuffer
+    from scanspaceimageprocessor_amd import _lib
+
+    ctx = default_context()
+    n, h, w = 5, 96, 128
+    rng = np.random.default_rng(5)
+    thumbs = np.stack([inputs.linear_image(90 + i, h, w) * np.float32(2.0 ** rng.uniform(-0.5, 0.5)) for i in range(n)])
+    want_b = [oc.image_brightness(x, 0.06, 0.96) for x in thumbs]
+    want_m = oc.exposure_multipliers(want_b, 2)
+    comm = ctx.comm_create(_lib.comm_unique_id(), 0, 1)
+    t = DeviceBuffer.from_array(ctx, thumbs)
+    local, everyone, mult = (DeviceBuffer(ctx, 4 * n) for _ in range(3))
+    try:
+        for form in ("0", "1"):
+            monkeypatch.setenv("SS_ALLGATHER_BROADCASTS", form)
+            ctx.upload(everyone.ptr, np.zeros(n, np.float32))
+            ctx.exposure_stats(t.ptr, h, w, n, 0.06, 0.96, None, local.ptr)
+            ctx.allgather_stats(comm, 0, 1, n, local.ptr, everyone.ptr)
+            ctx.exposure_multipliers(everyone.ptr, n, 2, 0, n, mult.ptr)
+            ctx.sync()
+            np.testing.assert_allclose(everyone.to_array((n,), np.float32), want_b, rtol=1e-6)
+            np.testing.assert_allclose(mult.to_array((n,), np.float32), want_m, rtol=1e-6)
+    finally:
+        ctx.comm_destroy(comm)
+        for b in (t, local, everyone, mult):
+            b.free()
+
+
+def test_abi_gather_serves_the_normaliser_class():
+    """dataset.AbiGather as the ``gather`` of an ExposureNormaliser: "rank 1 of 2" as in the test above, the local
+    part going through ss_allgather_stats on a one-rank communicator."""
+    import torch
+
+    from scanspaceimageprocessor_amd import _lib
+    from scanspaceimageprocessor_amd.dataset import AbiGather
+
+    ctx = default_context()
+    dev = torch.device("cuda", ctx.device)
+    n, h, w = 6, 96, 128
+    thumbs = np.stack([inputs.linear_image(170 + i, h, w) for i in range(n)])
+    t = torch.from_numpy(thumbs).to(dev)
+    want_b = [oc.image_brightness(x, 0.06, 0.96) for x in thumbs]
+    want_m = oc.exposure_multipliers(want_b, None)
+    comm = ctx.comm_create(_lib.comm_unique_id(), 0, 1)
+    try:
+        other = ExposureNormaliser(ctx, n, 0, 2, 0.06, 0.96, gather=lambda local, n_images: None)
+        other.ops.stats(t.data_ptr(), h, w, other.count, 0.06, 0.96, other.brightness)
+        one_rank = AbiGather(ctx, comm, 0, 1)
+
+        def gather(local, n_images):
+            mine = one_rank(local, local.numel())
+            ctx.sync()
+            return torch.cat([other.brightness, mine])
+
+        norm = ExposureNormaliser(ctx, n, 1, 2, 0.06, 0.96, gather=gather)
+        gains = norm.run(t[norm.first:].data_ptr(), h, w)
+        ctx.sync()
+        np.testing.assert_allclose(gains.cpu().numpy(), want_m[norm.first:], rtol=1e-6)
+    finally:
+        ctx.comm_destroy(comm)

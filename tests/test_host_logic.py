@@ -185,6 +185,20 @@ def test_worker_reports_errors_and_continues(tmp_path):
     assert [e[1] for e in events] == ["started", "error", "started", "error"]
 
 
+def test_c_abi_shard_range_is_the_python_one():
+    """ss_shard_range (what a host in another language calls) and dataset.shard_range agree everywhere."""
+    from scanspaceimageprocessor_amd import _lib
+
+    for n in (0, 1, 2, 7, 63, 64, 65, 1000):
+        for world in (1, 2, 3, 4, 8):
+            for r in range(world):
+                assert _lib.shard_range(n, r, world) == shard_range(n, r, world)
+    with pytest.raises(ValueError):
+        _lib.shard_range(4, 2, 2)
+    with pytest.raises(ValueError):
+        _lib.shard_range(-1, 0, 1)
+
+
 def test_shard_range_partitions_contiguously():
     for n in (0, 1, 7, 64, 1024, 1001):
         for world in (1, 2, 3, 8):
