@@ -336,7 +336,12 @@ int ss_resize_area_host(ss_ctx* ctx, const float* src_host, int32_t height, int3
  * candidates (cv2.connectedComponentsWithStats(mask, connectivity=8)) with an area of at least min_area pixels
  * (the reference hard-wires 200) are set to 0 in place.  img_dev: [batch][height][width][3] float32.
  * masked_count_dev: optional device uint64[batch], the number of pixels zeroed per image (the reference logs it).
- * The set of zeroed pixels is exactly the reference's for the same input values.  Asynchronous.
+ * The luminance 0.2126 r + 0.7152 g + 0.0722 b and its comparison with the limits are float64 arithmetic on the
+ * float32 pixel values: the set of zeroed pixels is the reference's when its image holds these very float32 values
+ * and numpy forms the luminance in float64 (chart mode: the corrected image is float64).  Where the reference's
+ * image is still float32 (no chart, exposure / white balance only) numpy < 2 forms the luminance and the comparison
+ * in float32, and where it is float64 with values float32 cannot hold, a pixel within one rounding of a limit can
+ * fall on the other side there - which can keep or drop a whole region whose area is about min_area.  Asynchronous.
  * Limits: width <= 65535, height * width < 2^31, batch <= 65535. */
 int ss_mask_regions(ss_ctx* ctx, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
                     double highlight_limit, int32_t min_area, uint64_t* masked_count_dev);

@@ -182,15 +182,100 @@ class ImageCorrectionWorker:
         return (self.exposure_adj != 0.0 or self.shadow_adj != 0.0 or self.highlight_adj != 0.0
                 or self.white_balance_adj != 5500 or self.denoise_strength != 0.0 or self.sharpen_amount != 0.0)
 
+    RAW_EXTENSIONS = ('.nef', '.cr2', '.cr3', '.dng', '.arw', '.raw')  # imageProcessorWorker.py:411
+
     def _extract_white_balance_from_exif(self, img_path: str) -> float:
-        """The reference re-opens the RAW file to estimate the as-shot temperature
-        (imageProcessorWorker.py:397-577, host I/O); this package takes it from
-        ``image_metadata_map[path]['current_wb']`` when the caller provides it, else daylight."""
+        """As-shot colour temperature of an image (imageProcessorWorker.py:397-427): the camera's white-balance
+        multipliers through LibRaw for RAW files, then an EXIF temperature through OpenImageIO, then daylight -
+        each outcome logged as the reference logs it.  A caller that knows the value already puts it in
+        ``image_metadata_map[path]['current_wb']`` and no file is opened."""
         meta = getattr(self, "image_metadata_map", {}).get(img_path) or {}
+        if meta.get('current_wb') is not None:
+            try:
+                wb = float(meta['current_wb'])
+                self.signals.log.emit(f"[WB] Using white balance from the image metadata map: {wb}K")
+                return wb
+            except (TypeError, ValueError):
+                self.signals.log.emit(f"[WB] Ignoring unusable current_wb {meta['current_wb']!r} for {img_path}")
+        cache = self.__dict__.setdefault("_wb_by_path", {})  # one look per file, however often the stages are asked for
+        if img_path not in cache:
+            cache[img_path] = self._read_white_balance(img_path)
+        return cache[img_path]
+
+    def _read_white_balance(self, img_path: str) -> float:
+        default_wb = 5500.0
         try:
-            return float(meta.get('current_wb', 5500.0))
-        except (TypeError, ValueError):
-            return 5500.0
+            if img_path.lower().endswith(self.RAW_EXTENSIONS):
+                wb = self._get_wb_from_rawpy(img_path)
+                if wb is not None:
+                    self.signals.log.emit(f"[WB] Found white balance from rawpy: {wb}K")
+                    return wb
+            wb = self._get_wb_from_oiio_exif(img_path)
+            if wb is not None:
+                self.signals.log.emit(f"[WB] Found white balance from EXIF: {wb}K")
+                return wb
+        except Exception as e:
+            self.signals.log.emit(f"[WB] Error reading white balance from {img_path}: {e}")
+        # (a white-balance target other than 5500 K now shifts the image relative to a daylight source: say so)
+        self.signals.log.emit(f"[WB] Using default white balance: {default_wb}K")
+        return default_wb
+
+    @staticmethod
+    def wb_temperature_from_multipliers(wb_coeffs):
+        """The reference's estimate of a colour temperature from camera white-balance multipliers
+        (imageProcessorWorker.py:443-473): red/blue ratio after normalising to green, three linear pieces, clamped
+        to 2000-12000 K.  None when the multipliers are unusable."""
+        if wb_coeffs is None or len(wb_coeffs) < 3:
+            return None
+        r_mult, g_mult, b_mult = wb_coeffs[0], wb_coeffs[1], wb_coeffs[2]
+        if not g_mult > 0:
+            return None
+        rb_ratio = (r_mult / g_mult) / (b_mult / g_mult + 1e-10)
+        if rb_ratio > 1.5:
+            temp = 2000 + (rb_ratio - 1.5) * 1000
+        elif rb_ratio > 1.0:
+            temp = 3000 + (rb_ratio - 1.0) * 4000
+        else:
+            temp = 5000 + (1.0 - rb_ratio) * 5000
+        return float(max(2000, min(12000, temp)))
+
+    def _get_wb_from_rawpy(self, img_path: str):
+        """``raw.camera_whitebalance`` -> temperature (imageProcessorWorker.py:429-478); None when unavailable."""
+        try:
+            import rawpy
+
+            with rawpy.imread(img_path) as raw:
+                return self.wb_temperature_from_multipliers(raw.camera_whitebalance)
+        except Exception as e:
+            self.signals.log.emit(f"[WB] Error reading rawpy white balance: {e}")
+        return None
+
+    def _get_wb_from_oiio_exif(self, img_path: str):
+        """A colour temperature among the EXIF attributes OpenImageIO reports (imageProcessorWorker.py:480-534)."""
+        try:
+            from OpenImageIO import ImageInput
+
+            img_input = ImageInput.open(img_path)
+            if not img_input:
+                return None
+            spec = img_input.spec()
+            img_input.close()
+            for field in ('Exif:ColorTemperature', 'Exif:WhiteBalance', 'EXIF:ColorTemperature', 'EXIF:WhiteBalance',
+                          'ColorTemperature', 'WhiteBalance'):
+                try:
+                    value = spec.getattribute(field)
+                except Exception:
+                    continue
+                if isinstance(value, str):
+                    try:
+                        value = float(value.replace('K', '').replace('k', '').strip())
+                    except ValueError:
+                        continue
+                if isinstance(value, (int, float)) and 1000 <= float(value) <= 12000:
+                    return float(value)
+        except Exception as e:
+            self.signals.log.emit(f"[WB] Error reading OIIO EXIF white balance: {e}")
+        return None
 
     # ------------------------------------------------------------------ fused device path
 
@@ -253,6 +338,8 @@ class ImageCorrectionWorker:
         ctx = default_context()
         raw16 = isinstance(raw_img_float, np.ndarray) and raw_img_float.dtype == np.uint16
         img = np.ascontiguousarray(raw_img_float, dtype=np.uint16 if raw16 else np.float32)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError(f"expected an (H, W, 3) image, got shape {img.shape}")
         h, w, _ = img.shape
         kind = self._out_kind(self.output_format)
         kw = self.chain_stages(img_path)
@@ -328,6 +415,8 @@ class ImageCorrectionWorker:
         modified in place like the reference's array; other dtypes come back as a float32 copy) and returns it."""
         ctx = default_context()
         arr = np.ascontiguousarray(corrected, dtype=np.float32)
+        if arr.ndim != 3 or arr.shape[2] != 3:
+            raise ValueError(f"expected an (H, W, 3) image, got shape {arr.shape}")
         h, w, _ = arr.shape
         buf = ctx.workspace("worker.dst", arr.nbytes)
         ctx.upload(buf, arr)

@@ -412,6 +412,9 @@ class Context:
         """Run the chain on a C-contiguous float32 array of shape (H, W, 3) or (B, H, W, 3).
         Returns ``(out, lab_detected)``; ``out`` may be supplied (e.g. from ``pinned_empty``)."""
         src = np.ascontiguousarray(src, dtype=np.float32)
+        if src.ndim not in (3, 4) or src.shape[-1] != 3 or src.size != desc.batch * desc.height * desc.width * 3:
+            raise ValueError(f"array of shape {src.shape} does not hold the descriptor's {desc.batch} image(s) of "
+                             f"{desc.height} x {desc.width} x 3")
         if out is None:
             out = np.empty(src.shape, dtype=OUT_DTYPES[desc.out_kind])
         elif (out.shape != src.shape or out.dtype != OUT_DTYPES[desc.out_kind] or not out.flags.c_contiguous

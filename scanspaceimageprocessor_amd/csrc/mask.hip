@@ -35,8 +35,8 @@ constexpr int kChunk = kRowThreads * kPxPerThread;
 
 // np: 0.2126 * c0 + 0.7152 * c1 + 0.0722 * c2 on float64 data, no contraction
 __device__ __forceinline__ bool is_candidate(const F3 p, double lo, double hi) {
-  const double lum = __dadd_rn(__dadd_rn(__dmul_rn(0.2126, (double)p.x), __dmul_rn(0.7152, (double)p.y)),
-                               __dmul_rn(0.0722, (double)p.z));
+  const double lum = add_rn(add_rn(mul_rn(0.2126, (double)p.x), mul_rn(0.7152, (double)p.y)),
+                               mul_rn(0.0722, (double)p.z));
   return lum <= lo || lum >= hi;
 }
 

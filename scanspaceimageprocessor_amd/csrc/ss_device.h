@@ -67,6 +67,25 @@ struct ChainParams {
   int dst2_encoded;  // 1 = SS_OUT_U8_SRGB, 0 = SS_OUT_U8_LINEAR
 };
 
+// Single operations with one rounding each, where the reference's numpy arithmetic must be followed to the bit.
+// (HIP's __fmul_rn / __dadd_rn and friends are plain operators on this toolchain, so the compiler fuses them into
+// multiply-adds like any other expression; the pragma is what keeps them apart, also after inlining.)
+template <class T>
+__device__ __forceinline__ T mul_rn(T x, T y) {
+#pragma clang fp contract(off)
+  return x * y;
+}
+template <class T>
+__device__ __forceinline__ T add_rn(T x, T y) {
+#pragma clang fp contract(off)
+  return x + y;
+}
+template <class T>
+__device__ __forceinline__ T sub_rn(T x, T y) {
+#pragma clang fp contract(off)
+  return x - y;
+}
+
 // The kernel's parameter block as its kernel-argument segment holds it (the block is every kernel's FIRST argument),
 // behind a pointer the compiler cannot see through: scalars read through it are loaded where they are used instead
 // of living in scalar registers (spilled to vector lanes, each reload a vector instruction) across a whole loop.

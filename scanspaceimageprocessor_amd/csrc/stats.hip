@@ -210,11 +210,12 @@ __global__ __launch_bounds__(256) void pct_select_kernel(uint32_t* __restrict__ 
 // numpy's _lerp: a + (b-a)*t, switching to b - (b-a)*(1-t) for t >= 0.5
 __device__ __forceinline__ double lerp_legacy(float a, float b, double t) {
   const double d = (double)(b - a);  // the subtraction happens in float32 first
-  return t >= 0.5 ? (double)b - d * (1.0 - t) : (double)a + d * t;
+  // (numpy multiplies, then adds: two roundings, so no fused multiply-add here)
+  return t >= 0.5 ? sub_rn((double)b, mul_rn(d, sub_rn(1.0, t))) : add_rn((double)a, mul_rn(d, t));
 }
 __device__ __forceinline__ float lerp_f32(float a, float b, float t) {
-  const float d = __fsub_rn(b, a);
-  return t >= 0.5f ? __fsub_rn(b, __fmul_rn(d, __fsub_rn(1.0f, t))) : __fadd_rn(a, __fmul_rn(d, t));
+  const float d = sub_rn(b, a);
+  return t >= 0.5f ? sub_rn(b, mul_rn(d, sub_rn(1.0f, t))) : add_rn(a, mul_rn(d, t));
 }
 
 // select after level 3, interpolation, inversion parameters
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void pct_final_kernel(uint32_t* __restrict__ h
     } else {
       const float pl = lerp_f32(a0, b0, (float)R.g_low);
       const float ph = lerp_f32(a1, b1, (float)R.g_high);
-      const float denom = fmaxf(__fsub_rn(ph, pl), 1e-3f);
+      const float denom = fmaxf(sub_rn(ph, pl), 1e-3f);
       p_low = pl;
       p_high = ph;
       lo = pl;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void exposure_partial_kernel(const float* __re
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_px; i += gridDim.x * 256) {
     const F3 v = s[i];
     // numpy evaluates (0.2126*R + 0.7152*G) + 0.0722*B in float32 without fused multiply-add
-    const float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.2126f, v.x), __fmul_rn(0.7152f, v.y)), __fmul_rn(0.0722f, v.z));
+    const float lum = add_rn(add_rn(mul_rn(0.2126f, v.x), mul_rn(0.7152f, v.y)), mul_rn(0.0722f, v.z));
     ts += (double)lum;
     tc += 1;
     if (lum > lo && lum < hi) {

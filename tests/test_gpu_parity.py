@@ -122,6 +122,29 @@ def _negative_params(images, low, high, legacy):
         detail.free()
 
 
+def test_negative_percentiles_known_answers_of_the_numpy1_lerp():
+    """numpy < 2's _lerp on float32 neighbours with a float64 weight, hand-computed: a + (b - a) t below t = 0.5,
+    b - (b - a)(1 - t) from 0.5 on, the difference taken in float32 first.  11 samples per channel: the values
+    k / 10 (red), their squares (green) and a constant (blue)."""
+    k = np.arange(11, dtype=np.float32)
+    img = np.stack([k / np.float32(10), (k / np.float32(10)) ** 2, np.full(11, 0.4, np.float32)], axis=-1)[None, None]
+    img = np.ascontiguousarray(img[:, :, ::-1][:, :, np.random.default_rng(0).permutation(11)])  # order must not matter
+    p, det = _negative_params(img, 0.25, 0.77, True)   # virtual indices 2.5 and 7.7
+    for c in range(3):
+        v = np.sort(img[0, 0, :, c])
+        a0, b0, a1, b1 = v[2], v[3], v[7], v[8]
+        want_low = float(b0) - float(np.float32(b0 - a0)) * (1.0 - 0.5)                 # t = 0.5: the upper form
+        t_hi = 10 * ((0.77 * 100.0) / 100.0) - 7
+        want_high = float(b1) - float(np.float32(b1 - a1)) * (1.0 - t_hi)               # t = 0.7
+        assert det[0].p_low[c] == want_low and det[0].p_high[c] == want_high
+        assert p[0, c] == np.float32(want_low)
+        assert p[0, 3 + c] == np.float32(1.0 / max(want_high - want_low, 1e-3))
+    p, det = _negative_params(img, 0.12, 0.34, True)   # virtual indices 1.2 and 3.4: the lower form twice
+    v = np.sort(img[0, 0, :, 1])
+    assert det[0].p_low[1] == float(v[1]) + float(np.float32(v[2] - v[1])) * (10 * ((0.12 * 100.0) / 100.0) - 1)
+    assert det[0].p_high[1] == float(v[3]) + float(np.float32(v[4] - v[3])) * (10 * ((0.34 * 100.0) / 100.0) - 3)
+
+
 @pytest.mark.parametrize("shape,low,high", [((96, 128), 0.05, 0.995), ((1100, 1300), 0.05, 0.995),
                                             ((700, 1000), 0.005, 0.995), ((64, 64), 0.0, 1.0), ((1, 1), 0.05, 0.995),
                                             # sample counts 3, 6, 35, 5063: no multiple of the 4 keys a lane loads at once

@@ -82,6 +82,34 @@ def test_percentile_rank_matches_numpy_index_arithmetic(legacy):
             assert g == float(eg), (n, frac)
 
 
+def test_percentile_rank_known_answers_of_the_numpy1_branch():
+    """Hand-computed cases of np.percentile's index arithmetic as numpy < 2 does it for float32 data (float64
+    throughout): virtual index (n - 1) q, floor / next neighbour, weight, the clamp at q = 1.  Independent of the
+    oracle's restatement."""
+    kat = [  # n, q -> lo, hi, gamma
+        (5, 0.5, 2, 3, 0.0),       # 4 * 0.5 = 2 exactly
+        (5, 0.0, 0, 1, 0.0),
+        (5, 1.0, 4, 4, 0.0),       # the upper bound: both neighbours are the last element
+        (1, 0.3, 0, 0, 0.0),       # a single value
+        (11, 0.25, 2, 3, 0.5),     # 10 * 0.25 = 2.5: the weight at which numpy's lerp switches form
+        (11, 0.75, 7, 8, 0.5),
+        (9, 0.125, 1, 2, 0.0),     # 8 * 0.125 = 1
+        (3, 0.75, 1, 2, 0.5),
+    ]
+    for n, q, lo, hi, g in kat:
+        assert _lib.percentile_rank(n, q, True) == (lo, hi, g), (n, q)
+    # not representable exactly: 296814 * 0.005 = 1484.07, 999 * 0.995 = 994.005
+    lo, hi, g = _lib.percentile_rank(296815, 0.005, True)
+    assert (lo, hi) == (1484, 1485) and abs(g - 0.07) < 1e-9
+    lo, hi, g = _lib.percentile_rank(1000, 0.995, True)
+    assert (lo, hi) == (994, 995) and abs(g - 0.005) < 1e-9
+    # numpy >= 2 rounds q and the index to float32: n - 1 = 2^24, q = 0.3 -> float32(0.3) = 10066330 / 2^25, so the
+    # index is 5033165 exactly; numpy < 2 keeps float64: 2^24 * 0.3 = 5033164.8
+    assert _lib.percentile_rank(16777217, 0.3, False) == (5033165, 5033166, 0.0)
+    lo, hi, g = _lib.percentile_rank(16777217, 0.3, True)
+    assert (lo, hi) == (5033164, 5033165) and abs(g - 0.8) < 1e-9
+
+
 def test_sample_step_matches_reference_rule():
     for h, w in [(1, 1), (96, 128), (1100, 1300), (4000, 6000), (5504, 8256), (499, 501), (500, 500), (1000, 1000)]:
         assert _lib.negative_sample_step(h, w) == oc.negative_sample_step(h, w)

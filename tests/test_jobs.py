@@ -79,3 +79,49 @@ def test_export_path_rules(tmp_path, monkeypatch):
     assert (tmp_path / "deep" / "er").is_dir()
     assert seen == dict(schema="[r]/[n]", input_path=p, output_base_dir=out, custom_name="c", image_number=3,
                         output_extension=".png", root_folder="", group_name="g")
+
+
+class _Log:
+    def __init__(self):
+        self.lines = []
+        self.log = types.SimpleNamespace(emit=self.lines.append)
+        self.status = self.preview = types.SimpleNamespace(emit=lambda *a: None)
+
+
+def test_as_shot_white_balance_follows_the_reference_estimate(monkeypatch):
+    """imageProcessorWorker.py:397-478: camera multipliers -> red/blue ratio -> three linear pieces, clamped; each
+    outcome logged; daylight (with its log line) when nothing is known."""
+    est = ipw.ImageCorrectionWorker.wb_temperature_from_multipliers
+    assert est([2.0, 1.0, 1.0, 1.0]) == 2000 + (2.0 / (1.0 + 1e-10) - 1.5) * 1000   # very warm
+    assert est([1.2, 1.0, 1.0]) == 3000 + (1.2 / (1.0 + 1e-10) - 1.0) * 4000   # warm to neutral
+    assert est([1.0, 1.0, 2.0]) == 5000 + (1.0 - 1.0 / (2.0 + 1e-10)) * 5000   # cool
+    assert est([30.0, 1.0, 1.0]) == 12000.0 and est([1.0, 0.0, 1.0]) is None and est([1.0, 1.0]) is None
+    assert est(None) is None
+
+    sig = _Log()
+    w = worker_from_job(ProcessingJob("j", "/in/a.nef", "/out/a.jpg", None, {}), sig)
+
+    class Raw:
+        camera_whitebalance = [2.1, 1.0, 1.4, 1.0]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setitem(sys.modules, "rawpy", types.SimpleNamespace(imread=lambda path: Raw()))
+    want = 3000 + (2.1 / (1.4 + 1e-10) - 1.0) * 4000
+    assert w._extract_white_balance_from_exif("/in/a.nef") == want
+    assert sig.lines[-1] == f"[WB] Found white balance from rawpy: {want}K"
+    # a value the caller already knows wins and opens no file
+    w.image_metadata_map = {"/in/a.nef": {"current_wb": 4300}}
+    assert w._extract_white_balance_from_exif("/in/a.nef") == 4300.0
+    # neither LibRaw nor EXIF: daylight, and the log says that it is a default
+    w.image_metadata_map = {}
+    monkeypatch.setitem(sys.modules, "rawpy", None)
+    monkeypatch.setitem(sys.modules, "OpenImageIO", None)
+    sig.lines.clear()
+    assert w._extract_white_balance_from_exif("/in/b.nef") == 5500.0
+    assert sig.lines[-1] == "[WB] Using default white balance: 5500.0K"
+    assert any(l.startswith("[WB] Error reading rawpy white balance") for l in sig.lines)
