@@ -286,9 +286,17 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       for (int k = 0; k <= MAIN; ++k) v[k] = F3{(float)(tid + k) * 1e-4f, (float)k * 1e-2f, 0.5f};
 #else
       const Lane l = lane_of(fresh_tid());
+      if (interior) {
+        // no reflection: a lane's pixels lie ROWS_PER_PASS rows apart, one multiplication serves them all
+        const uint32_t first = slot_src(t.x0, y0, true, 2 * r + l.m_row, r + l.m_col);
+        const uint32_t step = (uint32_t)ROWS_PER_PASS * (uint32_t)W * 12u;
 #pragma unroll
-      for (int k = 0; k < MAIN; ++k)
-        v[k] = pixel_at(s, slot_src(t.x0, y0, interior, 2 * r + ROWS_PER_PASS * k + l.m_row, r + l.m_col));
+        for (int k = 0; k < MAIN; ++k) v[k] = pixel_at(s, first + (uint32_t)k * step);
+      } else {
+#pragma unroll
+        for (int k = 0; k < MAIN; ++k)
+          v[k] = pixel_at(s, slot_src(t.x0, y0, false, 2 * r + ROWS_PER_PASS * k + l.m_row, r + l.m_col));
+      }
       if (l.s_on) v[MAIN] = pixel_at(s, slot_src(t.x0, y0, interior, 2 * r + l.s_row, l.s_lx));
 #endif
     }
