@@ -125,3 +125,80 @@ def test_as_shot_white_balance_follows_the_reference_estimate(monkeypatch):
     assert w._extract_white_balance_from_exif("/in/b.nef") == 5500.0
     assert sig.lines[-1] == "[WB] Using default white balance: 5500.0K"
     assert any(l.startswith("[WB] Error reading rawpy white balance") for l in sig.lines)
+
+
+def _project(tmp_out="/out"):
+    sw = np.linspace(0.05, 0.9, 72).reshape(24, 3).round(6).tolist()
+    return {
+        "metadata": {"export_format_version": "1.0"},
+        "processing_settings": {"output_directory": tmp_out, "export_format": ".tiff", "output_format": ".tiff",
+                                "tiff_bitdepth": 16, "exposure_adj": 0.25, "root_folder": "scan_042",
+                                "use_export_schema": False, "export_schema": ""},
+        "images": [
+            {"index": 0, "filename": "Group A", "full_path": "", "group": "A"},                       # a header row
+            {"index": 1, "filename": "a1.nef", "full_path": "/in/A/a1.nef", "group": "A", "selected": True},
+            {"index": 2, "filename": "b1.nef", "full_path": "/in/B/b1.nef", "group": "B", "selected": True},
+            {"index": 3, "filename": "a2.nef", "full_path": "/in/A/a2.nef", "group": "A", "selected": True},
+            {"index": 4, "filename": "hdr", "full_path": "/x", "group": "A", "metadata": {"is_group_header": True}},
+            {"index": 5, "filename": "c1.nef", "full_path": "/in/C/c1.nef", "group": "C", "selected": True},
+        ],
+        "image_groups": {
+            "A": {"has_calibration": True, "chart_swatches": sw, "chart_swatches_count": 24},
+            "B": {"has_calibration": True, "chart_swatches": (np.array(sw) * 0.9).tolist(), "chart_swatches_count": 24},
+            "C": {"has_calibration": False, "chart_swatches": [], "chart_swatches_count": 0},
+        },
+    }
+
+
+def test_jobs_of_a_saved_project_follow_the_server():
+    """image_space.py:1844-2100 (the exported structure) through networkProcessor.py:1166-1320: header rows and
+    images without a path are skipped, a group without 24 swatches fails its images, settings travel whole."""
+    from scanspaceimageprocessor_amd.ImageProcessor.jobs import jobs_from_project
+
+    ticks = iter(range(100, 200))
+    jobs, failed = jobs_from_project(_project(), clock=lambda: float(next(ticks)))
+    assert [j.image_path for j in jobs] == ["/in/A/a1.nef", "/in/B/b1.nef", "/in/A/a2.nef"]
+    assert [j.output_path for j in jobs] == ["/out/a1.tiff", "/out/b1.tiff", "/out/a2.tiff"]
+    assert len({j.job_id for j in jobs}) == 3 and all(j.job_id.startswith("proj_") for j in jobs)
+    assert jobs[0].swatches == _project()["image_groups"]["A"]["chart_swatches"]
+    assert jobs[1].swatches == _project()["image_groups"]["B"]["chart_swatches"]
+    assert jobs[0].settings["exposure_adj"] == 0.25
+    assert failed == [{"image_path": "/in/C/c1.nef", "group": "C",
+                       "error": "Group 'C' has invalid chart swatches (length: 0)"}]
+    w = worker_from_job(jobs[0])
+    assert w.use_chart and w.output_format == ".tiff" and w.tiff_bitdepth == 16 and w.exposure_adj == 0.25
+
+
+def test_project_naming_schema_gets_a_sequence_number_per_group(monkeypatch):
+    from scanspaceimageprocessor_amd.ImageProcessor.jobs import jobs_from_project
+
+    seen = []
+
+    def apply_naming_schema(**kw):
+        seen.append((kw["group_name"], kw["image_number"], kw["root_folder"], kw["output_extension"]))
+        return f"{kw['output_base_dir']}/{kw['group_name']}_{kw['image_number']:03d}{kw['output_extension']}"
+
+    pkg = types.ModuleType("ImageProcessor")
+    mod = types.ModuleType("ImageProcessor.fileNamingSchema")
+    mod.apply_naming_schema = apply_naming_schema
+    pkg.fileNamingSchema = mod
+    monkeypatch.setitem(sys.modules, "ImageProcessor", pkg)
+    monkeypatch.setitem(sys.modules, "ImageProcessor.fileNamingSchema", mod)
+    p = _project()
+    p["processing_settings"].update(use_export_schema=True, export_schema="[g]_[n3][e]")
+    jobs, _ = jobs_from_project(p)
+    assert [j.output_path for j in jobs] == ["/out/A_001.tiff", "/out/B_001.tiff", "/out/A_002.tiff"]
+    assert seen == [("A", 1, "scan_042", ".tiff"), ("B", 1, "scan_042", ".tiff"), ("A", 2, "scan_042", ".tiff")]
+
+
+def test_run_project_drives_one_worker_per_image(tmp_path, monkeypatch):
+    from scanspaceimageprocessor_amd.ImageProcessor import jobs as jobs_mod
+
+    ran = []
+    monkeypatch.setattr(ipw.ImageCorrectionWorker, "run", lambda self: ran.append((self.images[0], self.raw_loader)))
+    path = tmp_path / "project.json"
+    path.write_text(json.dumps(_project(str(tmp_path))))
+    loader = lambda p: None
+    jobs, failed = jobs_mod.run_project(str(path), raw_loader=loader)
+    assert [r[0] for r in ran] == [j.image_path for j in jobs] and all(r[1] is loader for r in ran)
+    assert len(failed) == 1
