@@ -112,3 +112,22 @@ def test_worker_export_methods_write_the_named_formats(tmp_path):
     np.testing.assert_array_equal(preview, np.uint8(np.clip(lin * 255.0, 0, 255)))
     back, attrs = iw.read_exr(str(tmp_path / "a.exr"))
     np.testing.assert_array_equal(back, lin)
+
+
+def test_jpeg_export_needs_nothing_the_image_lacks(tmp_path):
+    """'.jpg' through write_image and the worker's export_image_jpg (imageProcessorWorker.py:604-606) with the
+    encoder that is installed here (Pillow; imageio is preferred when present, as in the reference): the file decodes
+    to the right size, close to the input at quality 100, and a lower quality makes a smaller file."""
+    Image = pytest.importorskip("PIL.Image")
+    from scanspaceimageprocessor_amd.ImageProcessor import imageProcessorWorker as ipw
+
+    y, x = np.mgrid[0:96, 0:128]
+    arr = np.stack([(x * 2) % 256, (y * 2 + x) % 256, (x + y) % 256], axis=-1).astype(np.uint8)
+    iw.write_image(str(tmp_path / "a.jpg"), arr, ".jpg", jpeg_quality=100)
+    with Image.open(tmp_path / "a.jpg") as im:
+        back = np.asarray(im.convert("RGB"))
+    assert back.shape == arr.shape
+    assert np.mean(np.abs(back.astype(int) - arr.astype(int))) < 6.0
+    w = ipw.ImageCorrectionWorker(["a.nef"], None, str(tmp_path), None, output_format=".jpg", jpeg_quality=40)
+    w.export_image_jpg(arr, str(tmp_path / "b.jpg"))
+    assert 0 < (tmp_path / "b.jpg").stat().st_size < (tmp_path / "a.jpg").stat().st_size
