@@ -217,11 +217,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   // living in scalar registers, spilled to vector lanes, across the whole walk.  (The parameter block is the
   // kernel's first argument: offset 0 of the argument segment.)
   auto params_now = [&]() -> const ChainParams& {
-#ifdef SS_PLAIN_KERNARG
-    if constexpr (true) {
-#else
-    if constexpr (!PLAIN) {  // (the plain chain uses few enough parameters to keep them)
-#endif
+    if constexpr (!PLAIN) {  // (the plain chain uses few enough parameters to keep them: measured, no gain there)
       typedef const __attribute__((address_space(4))) ChainParams* KernargParams;
       KernargParams k = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(k));
