@@ -12,7 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libscanspace_hip.so")
 SOURCES = ["chain.hip", "usm.hip", "stats.hip", "resize.hip", "mask.hip", "lab.hip", "api.hip"]
-HEADERS = ["ss_device.h", "ss_internal.h", os.path.join("..", "..", "include", "scanspace.h")]
+# every header of the sources' directory: a change in any of them rebuilds every object
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "scanspace.h")]
 # The pixel pipelines pack their pair arithmetic explicitly (v_pk_*_f32).  The SLP vectoriser's own pairs need
 # aligned register pairs, and the copies it inserts for them wait on the pixel loads: without it the tile kernel's
 # phase 1 keeps its prefetch in flight and the pointwise chain gains 5 % (0.73 -> 0.77 of the HBM peak).

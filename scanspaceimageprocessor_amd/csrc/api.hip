@@ -207,6 +207,7 @@ int build_params(ss_ctx* c, const ss_chain_desc* d, ChainParams* P) {
     P->sh_shadow_amount = d->sh_shadow_amount;
     P->sh_highlight_amount = d->sh_highlight_amount;
     P->sh_falloff = d->sh_falloff_power;
+    P->sh_ln_falloff = log((double)d->sh_falloff_power);
     // the largest |g(f + d) - g(f)| this stage can produce: |L' - L| <= 100 (|ss| + |hs|) |falloff - 1| (and <= 100),
     // d = that / 116, f <= ~1; the chroma shrink moves fx, fz by up to 0.2 |fx - fy| more
     double dl = 100.0 * (fabs((double)P->sh_ss) + fabs((double)P->sh_hs)) * fabs((double)d->sh_falloff_power - 1.0);

@@ -65,6 +65,7 @@ struct ChainParams {
   // the output encoding (null = none).  Set by the launcher, read where the kernels store (through kernarg_params).
   unsigned char* dst2;
   int dst2_encoded;  // 1 = SS_OUT_U8_SRGB, 0 = SS_OUT_U8_LINEAR
+  double sh_ln_falloff;  // ln(sh_falloff) in float64, for the float64 re-evaluation (falloff ** x = exp(x ln falloff))
 };
 
 // Single operations with one rounding each, where the reference's numpy arithmetic must be followed to the bit.

@@ -1,5 +1,6 @@
 // Cycles one wave spends in careful_pixel (all 64 lanes active, different pixels), per chain.
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include "../../scanspaceimageprocessor_amd/csrc/ss_careful.h"
 using namespace ss;
@@ -33,7 +34,7 @@ int main() {
   P.n_gain = 1; P.gain[0][0] = P.gain[0][1] = P.gain[0][2] = 1.1f;
   ChainParams A = P; A.usm = 1; A.usm_amount = 50.0f;
   run("ccm + gain + usm", A);
-  ChainParams B = P; B.sh = 1; B.sh_shadow_amount = 0.5f; B.sh_highlight_amount = -0.5f; B.sh_falloff = 7.0f; B.sh_chroma = 1;
+  ChainParams B = P; B.sh = 1; B.sh_shadow_amount = 0.5f; B.sh_highlight_amount = -0.5f; B.sh_falloff = 7.0f; B.sh_ln_falloff = log(7.0); B.sh_chroma = 1;
   run("ccm + gain + s/h", B);
   ChainParams C = B; C.usm = 1; C.usm_amount = 40.0f;
   run("ccm + gain + s/h + usm", C);
