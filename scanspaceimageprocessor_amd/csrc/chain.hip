@@ -281,22 +281,27 @@ __global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, int l
   const size_t n_words = wpi * (size_t)batch;
   __shared__ unsigned long long words[256];
   __shared__ uint32_t start[257];
+  __shared__ uint32_t wave_total[4];
   for (size_t chunk = (size_t)blockIdx.x * 256; chunk < n_words; chunk += (size_t)gridDim.x * 256) {
     const size_t g = chunk + threadIdx.x;
     const unsigned long long w = g < n_words ? P.risk_bits[g] : 0ull;
     if (__syncthreads_or(w != 0ull) == 0) continue;
     words[threadIdx.x] = w;
-    // inclusive scan of the bit counts
-    uint32_t v = (uint32_t)__popcll(w);
-    start[threadIdx.x + 1] = v;
+    // inclusive scan of the bit counts: inside each wave by lane shifts, the four waves' totals through LDS
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = (uint32_t)__popcll(w);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t below = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d) incl += below;
+    }
+    if (lane == 63u) wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < wave; ++k) before += wave_total[k];
+    start[threadIdx.x + 1] = before + incl;
     if (threadIdx.x == 0) start[0] = 0;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      const uint32_t add = threadIdx.x + 1 > (uint32_t)d ? start[threadIdx.x + 1 - d] : 0u;
-      __syncthreads();
-      start[threadIdx.x + 1] += add;
-      __syncthreads();
-    }
     const uint32_t total = start[256];
     if (threadIdx.x == 0) atomicAdd(P.risk_count, total);
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
