@@ -351,7 +351,7 @@ struct RiskCfg {
   static constexpr bool ENCODED = OUT == SS_OUT_F32_SRGB || OUT == SS_OUT_U16_SRGB;
   static constexpr bool ENABLED = OUT == SS_OUT_F32_LINEAR || ENCODED;
   static constexpr float MIN_MX = ENCODED ? 0.1f / 3.3f : 1.29f / 3.3f;
-  static constexpr float RATIO = ENCODED ? 60.0f / 3.3f : 250.0f / 3.3f;
+  static constexpr float RATIO = ENCODED ? 100.0f / 3.3f : 400.0f / 3.3f;
 };
 constexpr float kRiskBelowZero = -4.0e-6f;
 
