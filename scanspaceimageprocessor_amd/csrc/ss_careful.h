@@ -27,27 +27,25 @@ __device__ __forceinline__ double spow(double a, double p) {
   return a < 0.0 ? -m : m;
 }
 // sign(a) |a|^(N/M) for the rational exponents of this chain (12/5, 5/12, 1/3): the float32 hardware estimate
-// exp2(N/M log2 |a|), good to ~1e-7 on the chain's domain, and one Newton step on y^M = |a|^N in float64, which
-// squares that error ((M - 1)/2 e^2: below 1e-12 relative against pow() between 1e-12 and 4, measured): a dozen
-// float64 multiplications and one division where pow() takes several hundred instructions (a pixel of the
-// sharpen chain: 752 vector instructions instead of 2444).  Arguments whose powers could leave float64's range
-// (or float32's, for the estimate) take pow().
+// exp2(N/M log2 |a|), good to ~1e-7, and one Newton step on y^M = |a|^N in float64, which squares that error
+// ((M - 1)/2 e^2: below 1e-12 relative against pow(), measured): a dozen float64 multiplications and one division
+// where pow() takes several hundred instructions (a pixel of the sharpen chain: 752 vector instructions instead of
+// 2444).  The argument is first scaled by 2^(M k) into [2^-M, 2^M], so that neither the float32 estimate nor the
+// powers inside the step can leave their ranges, and the result by 2^(-N k).
 template <int N, int M>
 __device__ __forceinline__ double rpow(double a) {
   if (a == 0.0) return 0.0;
-  const double x = fabs(a);
-  double y;
-  if (x < 1e-20 || x > 1e20) {
-    y = pow(x, (double)N / (double)M);
-  } else {
-    y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * ((float)N / (float)M));
-    double ym = y, xn = x;
+  const double x0 = fabs(a);
+  const int k = -(ilogb(x0) / M);
+  const double x = ldexp(x0, M * k);
+  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * ((float)N / (float)M));
+  double ym = y, xn = x;
 #pragma unroll
-    for (int k = 1; k < M; ++k) ym *= y;
+  for (int j = 1; j < M; ++j) ym *= y;
 #pragma unroll
-    for (int k = 1; k < N; ++k) xn *= x;
-    y -= y * (ym - xn) / ((double)M * ym);
-  }
+  for (int j = 1; j < N; ++j) xn *= x;
+  y -= y * (ym - xn) / ((double)M * ym);
+  y = ldexp(y, -N * k);
   return a < 0.0 ? -y : y;
 }
 __device__ __forceinline__ double encode(double L) { return L <= 0.0031308 ? L * 12.92 : 1.055 * rpow<5, 12>(L) - 0.055; }
