@@ -159,6 +159,9 @@ def main():
                     help="N > 1: the all-gather through torch.distributed (default) or through the library's own "
                          "ss_allgather_stats (RCCL resolved by the library; torch.distributed only carries the "
                          "communicator's identifier to the ranks)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 on a box with one GPU: every rank uses device 0 and the ranks talk over gloo (RCCL refuses "
+                         "two ranks on one device); exercises the multi-rank plumbing, its numbers mean nothing")
     ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
                     help="config2 = BASELINE.json configs[1] (default, the headline); config5 = the dataset-normalisation "
                          "scaling case: thumbnail statistics -> all-gather -> multipliers -> CCM + gain + sRGB, float32 "
@@ -180,11 +183,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     config5 = args.workload == "config5"
     if config5 and args.batch == 64:
@@ -219,7 +227,13 @@ def main():
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     gather = None
-    if world > 1 and args.collective == "abi":
+    if world > 1 and args.rehearse_on_one_gpu:
+        from scanspaceimageprocessor_amd.dataset import gather_brightness
+
+        def gather(local, n_images):  # gloo moves host tensors
+            torch.cuda.current_stream(dev).synchronize()
+            return gather_brightness(local.cpu(), n_images).to(dev)
+    elif world > 1 and args.collective == "abi":
         from scanspaceimageprocessor_amd import _lib
         from scanspaceimageprocessor_amd.dataset import AbiGather
 
@@ -261,7 +275,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -360,7 +374,7 @@ def main():
             "metric": "megapixels/sec (whole node), full 24MP correction chain",
             "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
                 "workload": (f"{B}x24MP per GPU: exposure normalisation + Cheung-2004 3x3 CCM + gain + clip + sRGB encode, "
                              "float32 out (the dataset-normalisation scaling case)") if config5 else
