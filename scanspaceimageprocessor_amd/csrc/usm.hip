@@ -91,11 +91,12 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
 // image covers whole, in an image of even width): no bounds tests, no alignment test, a 32-bit byte offset on the
 // image's base address (an image has at most 2^28 pixels).
 template <int OUT, bool UNIT>
-__device__ __forceinline__ void usm_store_pair_inside(void* dst_img, int W, int y, int x, const Px o0, const Px o1) {
+__device__ __forceinline__ void usm_store_pair_inside(void* dst_img, uint32_t byte_offset, const Px o0, const Px o1) {
   auto q16 = [](float v) -> uint32_t { return UNIT ? quant16_unit(v) : quant16(v); };
-  const uint32_t px = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+  auto q8 = [](float v) -> uint32_t { return UNIT ? quant8_unit(v) : quant8(v); };
+  char* at = reinterpret_cast<char*>(dst_img) + byte_offset;
   if constexpr (OUT == SS_OUT_F32_LINEAR || OUT == SS_OUT_F32_SRGB) {
-    F3* d = reinterpret_cast<F3*>(reinterpret_cast<char*>(dst_img) + px * 12u);
+    F3* d = reinterpret_cast<F3*>(at);
     store_stream(d, F3{o0.r, o0.g, o0.b});
     store_stream(d + 1, F3{o1.r, o1.g, o1.b});
   } else if constexpr (OUT == SS_OUT_U16_SRGB) {
@@ -103,9 +104,15 @@ __device__ __forceinline__ void usm_store_pair_inside(void* dst_img, int W, int 
     q.x = q16(o0.r) | (q16(o0.g) << 16);
     q.y = q16(o0.b) | (q16(o1.r) << 16);
     q.z = q16(o1.g) | (q16(o1.b) << 16);
-    store_stream(reinterpret_cast<U3*>(reinterpret_cast<char*>(dst_img) + px * 6u), q);
+    store_stream(reinterpret_cast<U3*>(at), q);
   } else {
-    usm_store_pair<OUT, UNIT>(dst_img, W, 1 << 30, y, x, o0, o1);
+    uint8_t* d = reinterpret_cast<uint8_t*>(at);
+    d[0] = (uint8_t)q8(o0.r);
+    d[1] = (uint8_t)q8(o0.g);
+    d[2] = (uint8_t)q8(o0.b);
+    d[3] = (uint8_t)q8(o1.r);
+    d[4] = (uint8_t)q8(o1.g);
+    d[5] = (uint8_t)q8(o1.b);
   }
 }
 
@@ -410,7 +417,12 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       const bool inside = x0 + TW <= W && y0 + TH <= H && (W & 1) == 0 && kernarg_params().dst2 == nullptr;
       // ---- phase 3: column pass, mask logic, Lab -> sRGB, encode, store ----
       // one pixel pair at a time: everything after the blur
-      auto pair_out = [&](int ly, int px, v2f blur) {
+      // (`inside_at`: byte offset of the pair's slot in the output image, used for tiles the image covers whole)
+      constexpr uint32_t PX_BYTES = 3u * OutTraits<OUT>::BYTES;
+      auto slot_at = [&](int ly, int px) -> uint32_t {
+        return ((uint32_t)(y0 + ly) * (uint32_t)W + (uint32_t)(x0 + px)) * PX_BYTES;
+      };
+      auto pair_out = [&](int ly, int px, v2f blur, uint32_t inside_at) {
         const float2 lc = *reinterpret_cast<const float2*>(Lt + (ly + r) * PW + r + px);
         const float* cq = C0 + ly * TW + px;
         const float2 c0 = *reinterpret_cast<const float2*>(cq), c1 = *reinterpret_cast<const float2*>(cq + CP),
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         asm volatile("" ::"v"(o.r.x), "v"(o.r.y), "v"(o.g.x), "v"(o.g.y), "v"(o.b.x), "v"(o.b.y));
 #else
         if (inside)
-          usm_store_pair_inside<OUT, PLAIN>(d, W, y0 + ly, x0 + px, px_lo(o), px_hi(o));
+          usm_store_pair_inside<OUT, PLAIN>(d, inside_at, px_lo(o), px_hi(o));
         else
           usm_store_pair<OUT, PLAIN>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
 #endif
@@ -503,9 +515,9 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s2 * TW], band[s2], acc, 0, 0, 0);
-        pair_out(lane & 15, c0 + 4 * (lane >> 4), v2f{acc[0], acc[1]});
+        pair_out(lane & 15, c0 + 4 * (lane >> 4), v2f{acc[0], acc[1]}, slot_at(lane & 15, c0 + 4 * (lane >> 4)));
         __builtin_amdgcn_sched_barrier(0);
-        pair_out(lane & 15, c0 + 4 * (lane >> 4) + 2, v2f{acc[2], acc[3]});
+        pair_out(lane & 15, c0 + 4 * (lane >> 4) + 2, v2f{acc[2], acc[3]}, slot_at(lane & 15, c0 + 4 * (lane >> 4) + 2));
       } else if constexpr (R_T != 0) {
         // a thread owns one pixel-pair column and RUN consecutive rows: the RUN + 2r row-filtered values it
         // needs are read once, all reads in flight together, and every output reuses 2r of them
@@ -536,9 +548,13 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
             }
           }
         }
+        // the run's output slots lie one image row apart: one multiplication for the first, additions after it
+        uint32_t at = slot_at(ly0, px);
+        const uint32_t row_bytes = (uint32_t)W * PX_BYTES;
 #pragma unroll
         for (int q = 0; q < RUN; ++q) {
-          pair_out(ly0 + q, px, blur[q]);
+          pair_out(ly0 + q, px, blur[q], at);
+          at += row_bytes;
           __builtin_amdgcn_sched_barrier(0);  // one pair's arithmetic at a time keeps the register count down
         }
       } else {
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
             t = *reinterpret_cast<const float2*>(col + j * TW);
             blur = mad<v2f>(v2f{t.x, t.y}, P.taps[j <= r ? j : 2 * r - j], blur);
           }
-          pair_out(ly, px, blur);
+          pair_out(ly, px, blur, slot_at(ly, px));
         }
       }
 
