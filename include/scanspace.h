@@ -341,10 +341,17 @@ int ss_resize_area_host(ss_ctx* ctx, const float* src_host, int32_t height, int3
  * and numpy forms the luminance in float64 (chart mode: the corrected image is float64).  Where the reference's
  * image is still float32 (no chart, exposure / white balance only) numpy < 2 forms the luminance and the comparison
  * in float32, and where it is float64 with values float32 cannot hold, a pixel within one rounding of a limit can
- * fall on the other side there - which can keep or drop a whole region whose area is about min_area.  Asynchronous.
+ * fall on the other side there - which can keep or drop a whole region whose area is about min_area
+ * (ss_mask_regions_f32 covers the float32 case).  Asynchronous.
  * Limits: width <= 65535, height * width < 2^31, batch <= 65535. */
 int ss_mask_regions(ss_ctx* ctx, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
                     double highlight_limit, int32_t min_area, uint64_t* masked_count_dev);
+/* The same with the luminance arithmetic chosen: float32_luminance != 0 forms 0.2126 r + 0.7152 g + 0.0722 b, and
+ * compares it with the limits rounded to float32, in float32 - what the reference's numpy < 2 does while its image
+ * is still float32 (imageProcessorWorker.py:989-993 behind a no-chart path with exposure / white balance only);
+ * 0 is ss_mask_regions. */
+int ss_mask_regions_f32(ss_ctx* ctx, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
+                        double highlight_limit, int32_t min_area, int32_t float32_luminance, uint64_t* masked_count_dev);
 
 /* ---- plain device memory helpers for hosts without another HIP binding -------------------- */
 

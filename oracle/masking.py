@@ -15,8 +15,18 @@ from __future__ import annotations
 import numpy as np
 
 
-def candidate_mask(corrected, shadow_limit=0.05, highlight_limit=0.98):
-    """imageProcessorWorker.py:989-996 (float64 luminance of the float64 image the reference holds there)."""
+def candidate_mask(corrected, shadow_limit=0.05, highlight_limit=0.98, float32_luminance=False):
+    """imageProcessorWorker.py:989-996.  By default the float64 luminance of the float64 image the reference holds
+    there in chart mode or behind a Lab edit.  ``float32_luminance``: the image is still float32 (no chart, exposure
+    and white balance only) and numpy < 2, the reference's pin, does not let Python scalars widen an array: the
+    products, their sum and the limits it is compared with are float32 (spelled out here, since this numpy may
+    promote differently)."""
+    if float32_luminance:
+        c = np.asarray(corrected, dtype=np.float32)
+        f = np.float32
+        lum = (f(0.2126) * c[:, :, 0] + f(0.7152) * c[:, :, 1]) + f(0.0722) * c[:, :, 2]
+        assert lum.dtype == np.float32
+        return (lum <= f(shadow_limit)) | (lum >= f(highlight_limit))
     c = np.asarray(corrected, dtype=np.float64)
     lum = 0.2126 * c[:, :, 0] + 0.7152 * c[:, :, 1] + 0.0722 * c[:, :, 2]
     return (lum <= shadow_limit) | (lum >= highlight_limit)
@@ -36,9 +46,9 @@ def clean_mask(mask, min_area=200):
     return keep[labels]
 
 
-def apply_masking(corrected, shadow_limit=0.05, highlight_limit=0.98, min_area=200):
+def apply_masking(corrected, shadow_limit=0.05, highlight_limit=0.98, min_area=200, float32_luminance=False):
     """Returns ``(masked image (copy), number of masked pixels)`` (imageProcessorWorker.py:1019-1020)."""
-    m = clean_mask(candidate_mask(corrected, shadow_limit, highlight_limit), min_area)
+    m = clean_mask(candidate_mask(corrected, shadow_limit, highlight_limit, float32_luminance), min_area)
     out = np.array(corrected, copy=True)
     out[m] = 0
     return out, int(m.sum())

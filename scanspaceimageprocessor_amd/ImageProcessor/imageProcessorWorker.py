@@ -402,13 +402,21 @@ class ImageCorrectionWorker:
         shadow_limit = getattr(self, "shadow_limit", 0.05)
         highlight_limit = getattr(self, "highlight_limit", 0.98)
         count_dev = ctx.workspace("worker.mask_count", 8)
-        ctx.mask_regions(img_dev, h, w, 1, shadow_limit, highlight_limit, self.MASK_MIN_AREA, count_dev)
+        ctx.mask_regions(img_dev, h, w, 1, shadow_limit, highlight_limit, self.MASK_MIN_AREA, count_dev,
+                         float32_luminance=self._reference_image_is_float32())
         count = np.zeros(1, dtype=np.uint64)
         ctx.download(count, count_dev)
         self.signals.log.emit(
             f"[Export Masked] Masked {int(count[0])} pixels (min area={self.MASK_MIN_AREA}) "
             f"with limits shadow<={shadow_limit:.2f}, highlight>={highlight_limit:.2f}"
         )
+
+    def _reference_image_is_float32(self) -> bool:
+        """Whether the array the reference masks is still float32 there: no chart (colour-science returns float64)
+        and no Lab edit (shadows / highlights, sharpen: float64 as well); exposure and white balance keep float32
+        (editingTools.py:435-466, 606-640).  Under the reference's numpy < 2 the luminance test is then float32."""
+        return (not self.use_chart and self.shadow_adj == 0.0 and self.highlight_adj == 0.0
+                and self.sharpen_amount == 0.0)
 
     def _apply_masking(self, corrected: np.ndarray) -> np.ndarray:
         """Host-array form with the reference's signature: zeroes the regions in ``corrected`` (float32 images are

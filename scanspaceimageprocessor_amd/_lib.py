@@ -117,6 +117,8 @@ SIGNATURES = {
     "ss_lab_to_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ss_mask_regions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                   C.c_int32, C.c_void_p]),
+    "ss_mask_regions_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                      C.c_int32, C.c_int32, C.c_void_p]),
     "ss_resize_area": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32]),
     "ss_resize_area_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
@@ -384,12 +386,14 @@ class Context:
         self.check(self.lib.ss_lab_to_rgb(self.handle, C.c_void_p(L_dev), C.c_void_p(a_dev), C.c_void_p(b_dev),
                                           int(n_pixels), C.c_void_p(rgb_dev)))
 
-    def mask_regions(self, img_dev, height, width, batch, shadow_limit, highlight_limit, min_area=200, count_dev=None):
+    def mask_regions(self, img_dev, height, width, batch, shadow_limit, highlight_limit, min_area=200, count_dev=None,
+                     float32_luminance=False):
         """Zero, in place, the 8-connected regions of at least ``min_area`` pixels whose luminance is <= shadow_limit
-        or >= highlight_limit (asynchronous).  ``count_dev``: optional device uint64[batch] of zeroed pixels."""
-        self.check(self.lib.ss_mask_regions(self.handle, C.c_void_p(img_dev), int(height), int(width), int(batch),
-                                            float(shadow_limit), float(highlight_limit), int(min_area),
-                                            C.c_void_p(count_dev or None)))
+        or >= highlight_limit (asynchronous).  ``count_dev``: optional device uint64[batch] of zeroed pixels.
+        ``float32_luminance``: luminance and comparison in float32, as numpy < 2 forms them for a float32 image."""
+        self.check(self.lib.ss_mask_regions_f32(self.handle, C.c_void_p(img_dev), int(height), int(width), int(batch),
+                                                float(shadow_limit), float(highlight_limit), int(min_area),
+                                                int(bool(float32_luminance)), C.c_void_p(count_dev or None)))
 
     def resize_area(self, src_dev, height, width, batch, dst_dev, dst_height, dst_width):
         """Area-average downscale of [batch][height][width][3] float32 on the device (asynchronous)."""

@@ -792,6 +792,12 @@ int ss_unpack_u16(ss_ctx* c, const uint16_t* src_dev, float* dst_dev, uint64_t n
 
 int ss_mask_regions(ss_ctx* c, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
                     double highlight_limit, int32_t min_area, uint64_t* masked_count_dev) {
+  return ss_mask_regions_f32(c, img_dev, height, width, batch, shadow_limit, highlight_limit, min_area, 0,
+                             masked_count_dev);
+}
+
+int ss_mask_regions_f32(ss_ctx* c, float* img_dev, int32_t height, int32_t width, int32_t batch, double shadow_limit,
+                        double highlight_limit, int32_t min_area, int32_t float32_luminance, uint64_t* masked_count_dev) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!img_dev) return fail(c, SS_ERR_INVALID, "img_dev must not be NULL");
@@ -802,7 +808,8 @@ int ss_mask_regions(ss_ctx* c, float* img_dev, int32_t height, int32_t width, in
     return fail(c, SS_ERR_INVALID, "limits must not be NaN");
   rc = grow(c, &c->ws_mask, &c->ws_mask_bytes, mask_workspace_bytes(batch, height, width));
   if (rc) return rc;
-  hipError_t e = launch_mask_regions(img_dev, height, width, batch, shadow_limit, highlight_limit, min_area, c->ws_mask,
+  hipError_t e = launch_mask_regions(img_dev, height, width, batch, shadow_limit, highlight_limit, min_area,
+                                     float32_luminance != 0, c->ws_mask,
                                      reinterpret_cast<unsigned long long*>(masked_count_dev), c->stream);
   if (e != hipSuccess) return fail(c, SS_ERR_HIP, "masking kernels failed to launch: %s", hipGetErrorString(e));
   return SS_OK;

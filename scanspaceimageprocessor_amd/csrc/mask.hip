@@ -33,11 +33,20 @@ constexpr int kRowThreads = 256;
 constexpr int kPxPerThread = 4;  // (2 ... 12 perform alike, 24 is 20 % slower)
 constexpr int kChunk = kRowThreads * kPxPerThread;
 
-// np: 0.2126 * c0 + 0.7152 * c1 + 0.0722 * c2 on float64 data, no contraction
+// np: 0.2126 * c0 + 0.7152 * c1 + 0.0722 * c2 and its comparison with the limits, no contraction.
+// F32 = false: float64 arithmetic on the float32 pixel values (the reference's image is float64: chart mode, or
+// any Lab edit).  F32 = true: what numpy < 2 does while the image is still float32 (no chart, exposure / white
+// balance only): the Python scalars do not widen the array, products, sums and limits are float32.
+template <bool F32>
 __device__ __forceinline__ bool is_candidate(const F3 p, double lo, double hi) {
-  const double lum = add_rn(add_rn(mul_rn(0.2126, (double)p.x), mul_rn(0.7152, (double)p.y)),
-                               mul_rn(0.0722, (double)p.z));
-  return lum <= lo || lum >= hi;
+  if constexpr (F32) {
+    const float lum = add_rn(add_rn(mul_rn(0.2126f, p.x), mul_rn(0.7152f, p.y)), mul_rn(0.0722f, p.z));
+    return lum <= (float)lo || lum >= (float)hi;
+  } else {
+    const double lum = add_rn(add_rn(mul_rn(0.2126, (double)p.x), mul_rn(0.7152, (double)p.y)),
+                              mul_rn(0.0722, (double)p.z));
+    return lum <= lo || lum >= hi;
+  }
 }
 
 // The run lists of one image.  Slots are numbered inside the image: slot = y * cap + k.
@@ -68,6 +77,7 @@ struct MaskWork {
 // contiguous).  The left flag comes from the neighbouring lane, across waves and stripes through LDS, across
 // chunks in a register; the number of a run inside its row is the count of starts to its left: lanes below
 // in the same wave (ballot), plus the totals of the waves and stripes before (LDS).
+template <bool F32>
 __global__ __launch_bounds__(kRowThreads) void mask_runs_kernel(const float* __restrict__ img, const MaskWork work,
                                                                 int h, int w, double lo, double hi) {
   constexpr int NW = kRowThreads / 64, P = kPxPerThread;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(kRowThreads) void mask_runs_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       const int x = x0 + k * kRowThreads + tid;
-      m[k] = x < w && is_candidate(load_stream(src + x), lo, hi);
+      m[k] = x < w && is_candidate<F32>(load_stream(src + x), lo, hi);
     }
 #pragma unroll
     for (int k = 0; k < P; ++k) {
@@ -356,7 +366,8 @@ MaskWork carve(void* workspace, int batch, int h, int w) {
 size_t mask_workspace_bytes(int batch, int h, int w) { return layout_of(batch, h, w).total; }
 
 hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shadow_limit, double highlight_limit,
-                               int min_area, void* workspace, unsigned long long* count_dev, hipStream_t st) {
+                               int min_area, bool float32_luminance, void* workspace, unsigned long long* count_dev,
+                               hipStream_t st) {
   if (h < 1 || w < 1 || w > kMaxWidth || batch < 1 || batch > 65535 || (int64_t)h * ((w + 1) / 2) > INT32_MAX)
     return hipErrorInvalidValue;
   const MaskWork work = carve(workspace, batch, h, w);
@@ -365,8 +376,12 @@ hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shado
     if (e != hipSuccess) return e;
   }
   // (rows go to the x dimension of the grid, which has no 65535 limit)
-  hipLaunchKernelGGL(mask_runs_kernel, dim3(h, batch), dim3(kRowThreads), 0, st, img, work, h, w, shadow_limit,
-                     highlight_limit);
+  if (float32_luminance)
+    hipLaunchKernelGGL(mask_runs_kernel<true>, dim3(h, batch), dim3(kRowThreads), 0, st, img, work, h, w, shadow_limit,
+                       highlight_limit);
+  else
+    hipLaunchKernelGGL(mask_runs_kernel<false>, dim3(h, batch), dim3(kRowThreads), 0, st, img, work, h, w, shadow_limit,
+                       highlight_limit);
   const unsigned row_blocks = (unsigned)(h < 2048 ? h : 2048);
   const size_t up_bytes = (size_t)work.cap * sizeof(uint32_t);
   const int stage = up_bytes <= 48 * 1024;

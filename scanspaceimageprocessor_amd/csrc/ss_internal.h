@@ -53,7 +53,8 @@ constexpr int kLabDetectBlocks = 1024;
 // are sized for the worst case); count_dev: optional [batch] counters.  w <= 65535.
 size_t mask_workspace_bytes(int batch, int h, int w);
 hipError_t launch_mask_regions(float* img, int h, int w, int batch, double shadow_limit, double highlight_limit,
-                               int min_area, void* workspace, unsigned long long* count_dev, hipStream_t st);
+                               int min_area, bool float32_luminance, void* workspace, unsigned long long* count_dev,
+                               hipStream_t st);
 
 // uint16 -> float32 / 65535 (chain.hip); src 16-byte aligned, dst 16-byte aligned
 hipError_t launch_unpack_u16(const uint16_t* src, float* dst, uint64_t n, hipStream_t st);

@@ -12,7 +12,7 @@ from scanspaceimageprocessor_amd import default_context
 pytestmark = pytest.mark.gpu
 
 
-def run_mask(imgs, shadow=0.05, highlight=0.98, min_area=200):
+def run_mask(imgs, shadow=0.05, highlight=0.98, min_area=200, float32_luminance=False):
     ctx = default_context()
     imgs = np.ascontiguousarray(imgs, dtype=np.float32)
     if imgs.ndim == 3:
@@ -21,7 +21,7 @@ def run_mask(imgs, shadow=0.05, highlight=0.98, min_area=200):
     buf = DeviceBuffer.from_array(ctx, imgs)
     cnt = DeviceBuffer(ctx, 8 * b)
     try:
-        ctx.mask_regions(buf.ptr, h, w, b, shadow, highlight, min_area, cnt.ptr)
+        ctx.mask_regions(buf.ptr, h, w, b, shadow, highlight, min_area, cnt.ptr, float32_luminance=float32_luminance)
         ctx.sync()
         return buf.to_array(imgs.shape, np.float32), cnt.to_array((b,), np.uint64)
     finally:
@@ -34,7 +34,8 @@ def check(imgs, **kw):
         imgs = imgs[None]
     got, counts = run_mask(imgs, **kw)
     for i in range(imgs.shape[0]):
-        want, n = om.apply_masking(imgs[i], kw.get("shadow", 0.05), kw.get("highlight", 0.98), kw.get("min_area", 200))
+        want, n = om.apply_masking(imgs[i], kw.get("shadow", 0.05), kw.get("highlight", 0.98), kw.get("min_area", 200),
+                                   kw.get("float32_luminance", False))
         np.testing.assert_array_equal(got[i], want.astype(np.float32))
         assert int(counts[i]) == n
 
@@ -177,3 +178,37 @@ def test_24mp_dark_background_with_an_object():
     img[holes] = 0.0
     img[1900:2100, 2900:3100] = 0.995                                   # a blown highlight patch
     check(img)
+
+
+def _pixels_on_the_limit(limit, seed):
+    """Colourful float32 pixels whose luminance is `limit` to within a float32 rounding, and their two tests."""
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    rg = rng.random((2000000, 2)).astype(np.float32) * f(0.2)
+    b = (limit - 0.2126 * rg[:, 0].astype(np.float64) - 0.7152 * rg[:, 1]) / 0.0722
+    ok = (b > 0) & (b < 1)
+    px = np.stack([rg[ok, 0], rg[ok, 1], b[ok].astype(np.float32)], axis=-1)
+    lum32 = (f(0.2126) * px[:, 0] + f(0.7152) * px[:, 1]) + f(0.0722) * px[:, 2]
+    lum64 = 0.2126 * px[:, 0].astype(np.float64) + 0.7152 * px[:, 1] + 0.0722 * px[:, 2]
+    return px, lum32 <= f(limit), lum64 <= limit
+
+
+@pytest.mark.parametrize("limit", [0.05, 0.06])   # float32(0.05) > 0.05, float32(0.06) < 0.06
+def test_luminance_in_float32_or_float64_at_the_limits(limit):
+    """Pixels whose luminance lands on the other side of the shadow limit in float32 than in float64 (numpy < 2
+    tests a float32 image in float32: no chart, exposure / white balance only; imageProcessorWorker.py:989-993):
+    a block of them, large enough to be a region, is zeroed in one mode and kept in the other, as the oracle says."""
+    px, in32, in64 = _pixels_on_the_limit(limit, 21)
+    differ = px[in32 != in64]
+    assert len(differ) >= 400, len(differ)
+    seen32 = bool((in32 & ~in64).sum() > (in64 & ~in32).sum())  # which test sees most of them as shadow
+    block = px[(in32 & ~in64) if seen32 else (in64 & ~in32)][:400].reshape(20, 20, 3)
+    rng = np.random.default_rng(22)
+    img = (0.3 + 0.4 * rng.random((64, 96, 3))).astype(np.float32)
+    img[4:24, 4:24] = block
+    for mode in (False, True):
+        check(img, shadow=limit, float32_luminance=mode)
+    got32, n32 = run_mask(img, shadow=limit, float32_luminance=True)
+    got64, n64 = run_mask(img, shadow=limit, float32_luminance=False)
+    assert (int(n32[0]), int(n64[0])) == ((400, 0) if seen32 else (0, 400))
+    assert got32[0, 4:24, 4:24].any() != seen32 and got64[0, 4:24, 4:24].any() == seen32

@@ -51,3 +51,17 @@ def test_apply_masking_zeroes_and_counts():
     out, n = om.apply_masking(img)
     assert n == 400 and (out[10:30, 10:30] == 0).all()
     np.testing.assert_array_equal(out[50:55, 50:55], img[50:55, 50:55])
+
+
+def test_float32_luminance_mode_rounds_products_sum_and_limit():
+    """numpy < 2 on a float32 image: 0.2126 * c0 etc. are float32 products, the limit is compared as float32.
+    float32(0.05) = 0.0500000007 lies above 0.05: a grey pixel of exactly that value is a shadow candidate in
+    float32 (lum == limit) and not in float64 (lum > 0.05)."""
+    f = np.float32
+    g = f(0.05)
+    img = np.full((1, 1, 3), g, dtype=np.float32)
+    lum32 = (f(0.2126) * g + f(0.7152) * g) + f(0.0722) * g
+    lum64 = 0.2126 * float(g) + 0.7152 * float(g) + 0.0722 * float(g)
+    assert om.candidate_mask(img, 0.05, 0.98, float32_luminance=True)[0, 0] == bool(lum32 <= f(0.05))
+    assert om.candidate_mask(img, 0.05, 0.98, float32_luminance=False)[0, 0] == bool(lum64 <= 0.05)
+    assert lum64 > 0.05  # (the float64 test never takes this pixel)
