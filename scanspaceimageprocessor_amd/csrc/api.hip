@@ -576,6 +576,8 @@ static int chain_run_two(ss_ctx* c, const ss_chain_desc* d, const float* src_dev
   ChainParams P;
   rc = build_params(c, d, &P);
   if (rc) return rc;
+  if (dst2_dev && P.lab_io)
+    return fail(c, SS_ERR_INVALID, "a chain on Lab data (lab_io) has no 8-bit second output: its values are not RGB");
   P.dst2 = (unsigned char*)dst2_dev;
   P.dst2_encoded = out_kind2 == SS_OUT_U8_SRGB ? 1 : 0;
   if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))

@@ -92,6 +92,9 @@ def test_second_output_arguments_are_checked():
             ctx.chain_run2(d, a.ptr, b.ptr, _lib.SS_OUT_U8_LINEAR, b.ptr)
         with pytest.raises(ScanSpaceError, match="dst2_dev"):
             ctx.chain_run2(d, a.ptr, b.ptr, _lib.SS_OUT_U8_LINEAR, 0)
+        with pytest.raises(ScanSpaceError, match="Lab data"):
+            ctx.chain_run2(make_desc(8, 8, 1, sh=(0.3, 0.0, 7.0), lab_io=True, out="f32"), a.ptr, b.ptr,
+                           _lib.SS_OUT_U8_LINEAR, c.ptr)
     finally:
         for x in (a, b, c):
             x.free()
