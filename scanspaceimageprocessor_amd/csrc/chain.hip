@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
           if (p1 < n) store_second(Pk.dst2, (size_t)img * n + p1, px_hi(f2), clip, enc);
         }
       }
-      const Px2 o2 = finish<OUT, false, v2f>(f2, P);
+      // (behind the shadows/highlights stage the pixel is already clipped - the stage ends in clip(encode(.)) - or
+      // it is Lab data, for which the descriptor cannot ask for a final clip: either way that clip has nothing to do)
+      const Px2 o2 = finish<OUT, SH, v2f>(f2, P);
       res[q] = px_lo(o2);
       res[q + 1] = px_hi(o2);
       if constexpr (SH && RiskCfg<OUT>::ENABLED) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
     if (px < n) {
       const F3 v = s[px];
       const ChainParams& P = params_now();
-      Px o = finish<OUT, false, float>(front<CCMC, SH, false, float>(Px{v.x, v.y, v.z}, P, ip, M), P);
+      Px o = finish<OUT, SH, float>(front<CCMC, SH, false, float>(Px{v.x, v.y, v.z}, P, ip, M), P);
       // (the main loop has already recorded these pixels and stored their second output: it evaluates every pixel,
       // it just does not store the first output of these)
       store_one<OUT>(d, px, o);
