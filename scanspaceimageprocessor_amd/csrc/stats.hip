@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void pct_sample_kernel(const float* __restrict
   uint32_t* smp = samples + (size_t)img * 3 * n;
   // four samples per trip: the gathers (one 12-byte load per sample, 9 or more pixels apart) are all issued before
   // the first key is binned
-  constexpr int kGather = 4;
+#ifndef SS_PCT_GATHER
+#define SS_PCT_GATHER 4
+#endif
+  constexpr int kGather = SS_PCT_GATHER;
   const uint32_t stride = gridDim.x * 256;
   for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += kGather * stride) {
     F3 v[kGather];
