@@ -278,3 +278,23 @@ def test_cache_hooks_of_the_preview_path_exist_and_hold_nothing():
     assert stats["entries"] == 0 and set(stats) == {"entries", "memory_mb", "memory_percent", "hits", "misses",
                                                     "evictions", "hit_rate"}
     assert et.check_memory_usage() is False
+
+
+def test_committed_bench_line_names_the_committed_counter_summary():
+    """The bench line quotes counter-derived figures from a file it names with its SHA-256: the committed line and
+    the committed file must belong together, and the figures in the line must be the file's."""
+    import hashlib
+    import json
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    line = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
+    roof = line["roofline"]
+    raw = open(os.path.join(root, roof["pmc_file"]), "rb").read()
+    assert hashlib.sha256(raw).hexdigest() == roof["pmc_sha256"]
+    pmc = json.loads(raw)
+    assert roof["valu_instructions_per_px"] == pmc["valu_per_px"] and roof["valu_trans_per_px"] == pmc["trans_per_px"]
+    assert roof["traffic"] == round((pmc["fetch_bytes_per_px"] + pmc["write_bytes_per_px"]) * roof["px_per_launch"])
+    assert roof["bound"] == "valu" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    for name in pmc["sources"]:
+        assert os.path.exists(os.path.join(root, "profiles", name))
+    assert {"threads4", "threads_all"} <= set(line["cpu_baseline"]) and len(line["others"]) >= 3
