@@ -141,8 +141,13 @@ extern "C" int ss_debug_usm_trace(void* out) {
 #endif
 
 template <int R_T, int CCMC, int OUT, bool PLAIN>
-__global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const StripWalk T,
+__global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const StripWalk T_arg,
                                                      const float* __restrict__ src, void* __restrict__ dst) {
+#ifdef SS_USM_WALK_IN_REGISTERS
+  constexpr bool PREFETCH_WALK = false;
+#else
+  constexpr bool PREFETCH_WALK = true;
+#endif
   constexpr int TW = USM_TW, TH = USM_TH, NT = USM_NT;
   extern __shared__ __attribute__((aligned(16))) float S[];
   __shared__ float4 M[ccm_needs_table<CCMC> ? SS_MAX_CCM_TERMS : 1];
@@ -243,7 +248,21 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
     int img, x0, ty, ty_end;
     bool valid, first;
   };
+  // The walk's description as the kernel-argument segment holds it (the second argument, behind the parameter
+  // block): it is read where a segment is drawn - once per eight tiles - and its seven scalars need not occupy
+  // registers in between (the scalar file is full: every value kept there pushes another into vector lanes).
+  auto walk_now = [&]() -> const StripWalk& {
+    if constexpr (PREFETCH_WALK) {
+      typedef const __attribute__((address_space(4))) char* KernargBytes;
+      KernargBytes k = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(k));
+      constexpr size_t at = (sizeof(ChainParams) + alignof(StripWalk) - 1) / alignof(StripWalk) * alignof(StripWalk);
+      return *(const StripWalk*)(const char*)(k + at);
+    }
+    return T_arg;
+  };
   auto seg_pos = [&](uint32_t seg) -> TilePos {
+    const StripWalk& T = walk_now();
     TilePos t;
     t.seg = seg;
     t.valid = seg < T.n_segments;
@@ -321,6 +340,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
   // i % 8 rule ever did not hold, only the locality would be lost.
   uint32_t probe = 0;  // ranges, counting from this workgroup's own, found exhausted so far (thread 0 only)
   auto draw = [&]() -> uint32_t {
+    const StripWalk& T = walk_now();
     const uint32_t home = blockIdx.x & 7u;
     while (probe < 8) {
       const uint32_t k = (home + probe) & 7u;
