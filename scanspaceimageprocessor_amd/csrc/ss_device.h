@@ -620,19 +620,28 @@ __device__ __forceinline__ PxT<V> ccm_rootpoly(const PxT<V> p, const int terms, 
       const V e[6] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb)};
       return ccm_dot<6, V>(e, M);
     }
+    // Degrees 3 and 4: spow is multiplicative (sign(x y) |x y|^p = spow(x, p) spow(y, p)), so every root of a
+    // product is a product of the three channels' own signed roots: 3 cube roots instead of 7, 3 fourth roots
+    // instead of 3 square and 9 fourth roots (each root a transcendental pair at 3.4 times a multiplication).
+    // The rounding of a term changes by an ulp or two either way, far inside what float32 leaves of these sums.
     case 13: {
+      const V cr = sroot3(R), cg = sroot3(G), cb = sroot3(B);
+      const V cr2 = cr * cr, cg2 = cg * cg, cb2 = cb * cb;
       const V e[13] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
-                       sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
-                       sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B)};
+                       cr * cg2, cg * cb2, cr * cb2, cg * cr2, cb * cg2, cb * cr2, (cr * cg) * cb};
       return ccm_dot<13, V>(e, M);
     }
     default: {  // 22
-      const V e[22] = {R, G, B, sroot2(rg), sroot2(gb), sroot2(rb),
-                       sroot3(rg * G), sroot3(gb * B), sroot3(rb * B),
-                       sroot3(rg * R), sroot3(gb * G), sroot3(rb * R), sroot3(rg * B),
-                       sroot4(R * R * rg), sroot4(R * R * rb), sroot4(G * G * rg),
-                       sroot4(G * G * gb), sroot4(B * B * rb), sroot4(B * B * gb),
-                       sroot4(R * rg * B), sroot4(G * rg * B), sroot4(B * rb * G)};
+      const V cr = sroot3(R), cg = sroot3(G), cb = sroot3(B);
+      const V cr2 = cr * cr, cg2 = cg * cg, cb2 = cb * cb;
+      const V qr = sroot4(R), qg = sroot4(G), qb = sroot4(B);       // signed fourth roots
+      const V hr = qr * vabs(qr), hg = qg * vabs(qg), hb = qb * vabs(qb);  // signed square roots
+      const V ar = vabs(hr), ag = vabs(hg), ab = vabs(hb);          // |x|^(1/2) = q^2
+      const V e[22] = {R, G, B, hr * hg, hg * hb, hr * hb,
+                       cr * cg2, cg * cb2, cr * cb2, cg * cr2, cb * cg2, cb * cr2, (cr * cg) * cb,
+                       (ar * qr) * qg, (ar * qr) * qb, (ag * qg) * qr,   // (R^3 G)^(1/4), (R^3 B), (G^3 R)
+                       (ag * qg) * qb, (ab * qb) * qr, (ab * qb) * qg,   // (G^3 B), (B^3 R), (B^3 G)
+                       ar * (qg * qb), ag * (qr * qb), ab * (qr * qg)};  // (R^2 G B), (G^2 R B), (B^2 R G)
       return ccm_dot<22, V>(e, M);
     }
   }
