@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Copy the results of tools/pmc_bench.sh TAG (gpurun_out/TAG_bench) into profiles/ and print the numbers the
+documents quote: tools/refresh_profiles.py [TAG]"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join("gpurun_out", f"{tag}_bench")
+for name in (f"{tag}_usm_pmc.json", f"{tag}_usm_pmc_sq.csv", f"{tag}_usm_pmc_fetch.csv", f"{tag}_usm_pmc_write.csv"):
+    shutil.copy(os.path.join(src, name), os.path.join("profiles", name))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join("profiles", f"{tag}_bench_line.json"))
+shutil.copy(os.path.join(src, "bench_traced.json"), os.path.join("profiles", f"{tag}_bench_line_under_rocprof.json"))
+rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
+with open(os.path.join("profiles", f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+    w.writerow(rows[0].keys())
+    for r in rows:
+        if len(r["Name"]) > 160:  # the framework's kernel names run to kilobytes
+            r["Name"] = r["Name"][:157] + "..."
+        w.writerow(r.values())
+u = [r for r in rows if "usm_kernel" in r["Name"]][0]
+d = json.load(open(os.path.join("profiles", f"{tag}_bench_line.json")))
+pm = json.load(open(os.path.join("profiles", f"{tag}_usm_pmc.json")))
+print("value", d["value"], "ms/step", d["ms_per_step"], "kernel_ms", d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"],
+      "achieved", d["roofline"]["achieved"], "valu_frac", d["roofline"]["valu_frac"])
+print("trace: usm_kernel", u["Calls"], "launches, average", float(u["AverageNs"]) / 1e6, "ms")
+print("pmc:", {k: pm[k] for k in ("clock_ghz", "valu_per_px", "trans_per_px", "valu_busy", "fetch_bytes_per_px", "write_bytes_per_px")})
+for e in d["others"]:
+    print(f'{e["kernel_ms"]:9.4f} ms  frac {e["frac"]:.4f}  {e["config"][:80]}')
+print("cpu:", d["cpu_baseline"]["value"], d["cpu_baseline"]["threads4"]["value"], d["cpu_baseline"]["threads_all"]["value"])
