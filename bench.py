@@ -69,11 +69,12 @@ def synthetic_swatches():
     return M_T.astype(np.float32), M_R.astype(np.float64)
 
 
-def cpu_baseline(amount, n_images=3):
+def cpu_baseline(amount, n_images=3, check=None):
     """Time the numpy restatement of the reference path on a bounded sample of the workload: `n_images` of the
     64 images single-threaded (about 4.5 s each on the GPU box's host; this is the reported baseline), then
     one image on each of 4 threads, the reference's default worker count (`threads4`).  Inputs are generated
-    outside the timed regions."""
+    outside the timed regions.  `check(image, gain)`: the library's 16-bit result for the same image; the first
+    image's restatement output is compared with it (untimed) and the comparison reported as `parity_check`."""
     from oracle import chain as oc
     from oracle import inputs
 
@@ -84,9 +85,13 @@ def cpu_baseline(amount, n_images=3):
     M_T, M_R = inputs.synthetic_swatches()
     imgs = [inputs.linear_image(1234 + i, H, W) for i in range(n_images)]
 
+    first_result = []
+
     def run_all():
         for img in imgs:
-            oc.config2(img, M_T, M_R, 1.1, amount, 2.0, 0.0)
+            r = oc.config2(img, M_T, M_R, 1.1, amount, 2.0, 0.0)
+            if not first_result:
+                first_result.append(r)
 
     t0 = time.perf_counter()
     if threadpool_limits is not None:
@@ -132,7 +137,16 @@ def cpu_baseline(amount, n_images=3):
     else:
         run_all_cores()
     dt_all = time.perf_counter() - t2
+    parity = None
+    if check is not None:
+        got = check(imgs[0], 1.1).astype(np.int32)
+        diff = np.abs(got - first_result[0].astype(np.int32))
+        parity = {"input": f"oracle.inputs.linear_image(1234), {H}x{W}, gain 1.1, sharpen amount {amount:g}: every value of "
+                           "the library's 16-bit output against the restatement's",
+                  "values": int(diff.size), "differing_values": int(np.count_nonzero(diff)),
+                  "max_abs_diff_lsb16": int(diff.max())}
     return {
+        "parity_check": parity,
         "value": round(n_images * H * W / 1e6 / dt, 3), "unit": "MP/s", "cores": 1, "kind": "port",
         "sample": f"{n_images} of the 64 images of {H}x{W} (24 MP) through oracle.chain.config2 (float64 numpy restatement "
                   f"of the reference CPU path, BLAS limited to 1 thread), {dt:.1f} s; host has {os.cpu_count()} logical CPUs",
@@ -413,7 +427,16 @@ def main():
         if world == 1 and not args.no_others and not config5:
             line["others"] = others()
         if world == 1 and not args.no_cpu_baseline and not config5:
-            line["cpu_baseline"] = cpu_baseline(args.amount)
+            def library_result(img, gain):
+                """The same chain through the library for one host image (the restatement's own input)."""
+                src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).to(dev)
+                dst = torch.empty((1, H, W, 3), dtype=torch.int16, device=dev)
+                d = make_desc(H, W, 1, ccm=ccm, gains=[gain], usm=(args.amount, 2.0, 0.0), final_clip=True, out="u16")
+                ctx.chain_run(d, src.data_ptr(), dst.data_ptr())
+                ctx.sync()
+                return dst[0].cpu().numpy().view(np.uint16)
+
+            line["cpu_baseline"] = cpu_baseline(args.amount, check=library_result)
         print(json.dumps(line), flush=True)
 
     if world > 1:
