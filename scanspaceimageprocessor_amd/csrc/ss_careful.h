@@ -28,10 +28,14 @@ __device__ __forceinline__ double spow(double a, double p) {
 }
 // sign(a) |a|^(N/M) for the rational exponents of this chain (12/5, 5/12, 1/3): the float32 hardware estimate
 // exp2(N/M log2 |a|), good to ~1e-7, and one Newton step on y^M = |a|^N in float64, which squares that error
-// ((M - 1)/2 e^2: below 1e-12 relative against pow(), measured): a dozen float64 multiplications and one division
-// where pow() takes several hundred instructions (a pixel of the sharpen chain: 752 vector instructions instead of
-// 2444).  The argument is first scaled by 2^(M k) into [2^-M, 2^M], so that neither the float32 estimate nor the
-// powers inside the step can leave their ranges, and the result by 2^(-N k).
+// ((M - 1)/2 e^2: below 1e-12 relative against pow(), measured): a dozen float64 multiplications where pow() takes
+// several hundred instructions.  The step's quotient (y^M - x^N) / (M y^M) is itself of size e, so the float32
+// reciprocal of its denominator (good to 1e-7) serves: it puts e * 1e-7 on the result, as little as the step's own
+// remainder, and a float64 division is some thirty instructions.  The argument is first scaled by 2^(M k) into
+// [2^-M, 2^M], so that neither the float32 estimates nor the powers inside the step can leave their ranges
+// (y^M stays inside 2^+-60), and the result by 2^(-N k).
+// Divisions by constants are written as multiplications by the constant's reciprocal throughout this file for the
+// same reason: a rounding of 1e-16 either way, where results are needed to 1e-9.
 template <int N, int M>
 __device__ __forceinline__ double rpow(double a) {
   if (a == 0.0) return 0.0;
@@ -44,13 +48,13 @@ __device__ __forceinline__ double rpow(double a) {
   for (int j = 1; j < M; ++j) ym *= y;
 #pragma unroll
   for (int j = 1; j < N; ++j) xn *= x;
-  y -= y * (ym - xn) / ((double)M * ym);
+  y -= y * (ym - xn) * (double)__builtin_amdgcn_rcpf((float)M * (float)ym);
   y = ldexp(y, -N * k);
   return a < 0.0 ? -y : y;
 }
 __device__ __forceinline__ double encode(double L) { return L <= 0.0031308 ? L * 12.92 : 1.055 * rpow<5, 12>(L) - 0.055; }
 __device__ __forceinline__ double decode(double V) {
-  return V <= 12.92 * 0.0031308 ? V / 12.92 : rpow<12, 5>((V + 0.055) / 1.055);
+  return V <= 12.92 * 0.0031308 ? V * (1.0 / 12.92) : rpow<12, 5>((V + 0.055) * (1.0 / 1.055));
 }
 __device__ __forceinline__ double lab_f(double t) {
   const double T = 24.0 / 116.0;
@@ -67,10 +71,10 @@ struct Lab3 {
 // colour.sRGB_to_XYZ (decode first) and colour.XYZ_to_Lab under D65
 __device__ __forceinline__ Lab3 rgb_to_lab(const double rgb[3]) {
   const double m[9] = {0.4124, 0.3576, 0.1805, 0.2126, 0.7152, 0.0722, 0.0193, 0.1192, 0.9505};
-  const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
+  const double inv_white[3] = {0.3290 / 0.3127, 1.0, 0.3290 / (1.0 - 0.3127 - 0.3290)};
   const double r = decode(rgb[0]), g = decode(rgb[1]), b = decode(rgb[2]);
   double f[3];
-  for (int k = 0; k < 3; ++k) f[k] = lab_f((m[3 * k] * r + m[3 * k + 1] * g + m[3 * k + 2] * b) / white[k]);
+  for (int k = 0; k < 3; ++k) f[k] = lab_f((m[3 * k] * r + m[3 * k + 1] * g + m[3 * k + 2] * b) * inv_white[k]);
   return Lab3{116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])};
 }
 
@@ -78,7 +82,7 @@ __device__ __forceinline__ Lab3 rgb_to_lab(const double rgb[3]) {
 __device__ __forceinline__ void lab_to_rgb(const Lab3 q, double rgb[3]) {
   const double inv[9] = {3.2406, -1.5372, -0.4986, -0.9689, 1.8758, 0.0415, 0.0557, -0.2040, 1.0570};
   const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
-  const double fy = (q.L + 16.0) / 116.0, fx = q.a / 500.0 + fy, fz = fy - q.b / 200.0;
+  const double fy = (q.L + 16.0) * (1.0 / 116.0), fx = q.a * (1.0 / 500.0) + fy, fz = fy - q.b * (1.0 / 200.0);
   const double x = lab_finv(fx) * white[0], y = lab_finv(fy) * white[1], z = lab_finv(fz) * white[2];
   for (int k = 0; k < 3; ++k) rgb[k] = clip01(encode(inv[3 * k] * x + inv[3 * k + 1] * y + inv[3 * k + 2] * z));
 }
@@ -206,7 +210,7 @@ __device__ inline void careful_pixel(const ChainParams* P, int img, float sr, fl
   }
   if (P->sh) {  // stage 4 (editingTools.py:508-541)
     Lab3 q = rgb_to_lab(p);
-    const double Ln = q.L / 100.0;
+    const double Ln = q.L * 0.01;
     const double ss = (double)P->sh_shadow_amount * 0.05, hs = (double)P->sh_highlight_amount * 0.05;
     // falloff ** x as exp(x ln falloff), the logarithm taken once on the host (pow() is three times the work)
     const double lf = P->sh_ln_falloff;
@@ -215,7 +219,7 @@ __device__ inline void careful_pixel(const ChainParams* P, int img, float sr, fl
     const double total = (h_adj + s_adj) * 100.0;
     q.L = fmin(fmax(q.L + total, 0.0), 100.0);
     if (P->sh_chroma) {
-      const double cs = 1.0 - fmin(fmax(fabs(total) / 20.0 * 0.05, 0.0), 0.2);
+      const double cs = 1.0 - fmin(fmax(fabs(total) * (0.05 / 20.0), 0.0), 0.2);
       q.a *= cs;
       q.b *= cs;
     }
@@ -223,9 +227,9 @@ __device__ inline void careful_pixel(const ChainParams* P, int img, float sr, fl
   }
   if (P->usm) {  // stage 5 (editingTools.py:745-817)
     Lab3 q = rgb_to_lab(p);
-    const double Ln = q.L / 100.0;
+    const double Ln = q.L * 0.01;
     const double amount = (double)P->usm_amount;
-    const double thr = (double)P->usm_threshold / 100.0;
+    const double thr = (double)P->usm_threshold * 0.01;
     double um = Ln - (double)Lb;
     if (thr > 0.0) {
       const double es = fabs(um);
@@ -234,9 +238,9 @@ __device__ inline void careful_pixel(const ChainParams* P, int img, float sr, fl
     const double hm = Ln > 0.9 ? 1.0 - (Ln - 0.9) * 10.0 : 1.0;
     const double sm = Ln < 0.1 ? Ln * 10.0 : 1.0;
     const double ad = fmin(fmax(hm * sm, 0.1), 1.0);
-    q.L = clip01(Ln + um * (amount / 50.0) * ad) * 100.0;
+    q.L = clip01(Ln + um * (amount * 0.02) * ad) * 100.0;
     if (amount > 30.0) {
-      const double boost = 1.0 + fabs(um) * (amount / 100.0) * 0.1;
+      const double boost = 1.0 + fabs(um) * (amount * 0.01) * 0.1;
       q.a = fmin(fmax(q.a * boost, -127.0), 127.0);
       q.b = fmin(fmax(q.b * boost, -127.0), 127.0);
     }

@@ -32,6 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--requeued", action="store_true", help="print how many pixels the last chain call evaluated again in float64")
     ap.add_argument("--configs", default="1,2,2b,3,4,4b")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -62,6 +63,9 @@ def main():
         gbs = bytes_px * b * h * w / (ms * 1e-3) / 1e9
         print(f"{name:34s} {b}x{h}x{w}  {ms:8.3f} ms (min {ms_min:8.3f})  {mp / (ms * 1e-3):10.0f} MP/s  "
               f"{gbs:7.0f} GB/s algorithmic = {gbs / 8000:.3f} of HBM peak", flush=True)
+        if args.requeued:
+            q = ctx.chain_requeued()
+            print(f"     evaluated again in float64 by the last chain call: {q} pixels = {100.0 * q / (b * h * w):.2f} %", flush=True)
 
     todo = args.configs.split(",")
     H, W, B = 4000, 6000, args.batch
