@@ -8,6 +8,7 @@ statistics, [RCCL all-gather when N > 1], multipliers) -> ColorChecker CCM (Cheu
 16-bit truncating quantise.  One "step" = one pass over the batch.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
+  python bench.py --gpus N --steps K --warmup W       (starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -159,6 +160,52 @@ def cpu_baseline(amount, n_images=3, check=None):
     }
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start one child process per rank and relay rank 0's line.
+
+    Runs before this process has imported torch or touched HIP: the parent only probes a free port, starts the
+    children (this same file, or the program named by SS_BENCH_RANK_PROGRAM, which the launcher's CPU test sets to a
+    stub) with RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment,
+    waits for all of them and returns the first non-zero exit status.  A failed child is not started again; when
+    one fails the others are terminated (they would wait in a collective for it)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    program = os.environ.get("SS_BENCH_RANK_PROGRAM", os.path.abspath(__file__))
+    children = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        # rank 0's stdout is this process's stdout (its one JSON line); the other ranks print nothing there
+        children.append(subprocess.Popen([sys.executable, "-u", program, *argv], env=env,
+                                         stdout=None if r == 0 else subprocess.DEVNULL))
+    status = 0
+    stopped_at = None
+    pending = dict(enumerate(children))
+    while pending:
+        for r, p in list(pending.items()):
+            rc = p.poll()
+            if rc is None:
+                continue
+            del pending[r]
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 128 - rc
+                print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+                for q in pending.values():
+                    q.terminate()
+                stopped_at = time.monotonic()
+        if pending:
+            if stopped_at is not None and time.monotonic() - stopped_at > 10.0:
+                for q in pending.values():  # a rank stuck in a device call does not see SIGTERM
+                    q.kill()
+            time.sleep(0.05)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +229,10 @@ def main():
                          "out, 128 images per GPU unless --batch is given")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (nothing here has touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -199,6 +250,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
     if args.rehearse_on_one_gpu:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank} needs GPU {local_rank} but this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
