@@ -151,7 +151,10 @@ const char* ss_version(void);
 
 /* Fused chain on device-resident data (asynchronous).  src_dev: [batch][H][W][3] float32.
  * dst_dev: same shape, element type given by out_kind (float32 / uint16 / uint8).
- * src_dev == dst_dev is allowed only for float32 outputs with usm_enabled == 0.
+ * src_dev == dst_dev is allowed only for float32 outputs of chains without a Lab edit (sh_enabled == 0 and
+ * usm_enabled == 0): narrower outputs and the unsharp mask read pixels other lanes have overwritten by then, and the
+ * float64 re-evaluation of a shadows/highlights chain (see ss_chain_requeued) reads the source again.  Anything else
+ * in place is refused with SS_ERR_INVALID.
  * Replaces, for one batch: ImageCorrectionWorker.run steps 5-7 (imageProcessorWorker.py:855-923),
  * apply_all_adjustments (editingTools.py:823-909) and its callees. */
 int ss_chain_run(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev);
@@ -278,7 +281,8 @@ int ss_comm_create(ss_ctx* ctx, const char id[SS_COMM_ID_BYTES], int32_t rank, i
 int ss_comm_destroy(ss_ctx* ctx, void* comm);
 
 /* Brightness of all n_images in image order on every rank: local_dev holds this rank's ss_shard_range(n_images, rank,
- * world) values, all_dev receives n_images values (all_dev may not overlap local_dev).  `comm`: an ncclComm_t of
+ * world) values (may be NULL on a rank whose range is empty, i.e. with fewer images than ranks: that rank still has
+ * to make the call), all_dev receives n_images values (all_dev may not overlap local_dev).  `comm`: an ncclComm_t of
  * `world` ranks in which this process is `rank` - from ss_comm_create, or the host's own communicator when it was
  * made by the same RCCL library.  Even shards go out as one all-gather, uneven ones as one group of broadcasts;
  * 4 bytes per image, latency-bound.  Queued on the context's stream behind ss_exposure_stats (asynchronous). */

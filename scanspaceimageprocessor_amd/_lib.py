@@ -144,34 +144,64 @@ class ScanSpaceError(RuntimeError):
         self.code = code
 
 
-def _share_torch_hip_runtime():
+_hip_runtime_choice = None  # which HIP runtime load_library() arranged for: see hip_runtime_choice()
+
+
+def _share_torch_hip_runtime(share):
     """One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7)
     and ask for it by the unversioned file name: loaded AFTER the system runtime this library links to, that is a
     second runtime in the process, whose initialisation finds no GPU ("No HIP GPUs are available").  Loaded
-    first, it satisfies this library's dependency by soname and both share it.  So when torch is installed and
-    not yet imported, its runtime is loaded here, before the library.  SCANSPACE_SYSTEM_HIP=1 keeps the system
-    runtime (for processes that never import torch)."""
+    first, it satisfies this library's dependency by soname and both share it.
+
+    Ordering rule for hosts: a process that uses torch beside this library either imports torch BEFORE the library
+    is loaded (nothing to do here then: torch's runtime is in the process already), or asks for the preload
+    (``load_library(share_torch_hip=True)`` or SCANSPACE_SHARE_TORCH_HIP=1).  Nothing is preloaded otherwise: a
+    process that never imports torch keeps the system runtime the library was built and linked against, and no
+    second copy of the HIP symbols is made global."""
+    global _hip_runtime_choice
     import importlib.util
+    import logging
     import sys
 
-    if "torch" in sys.modules or os.environ.get("SCANSPACE_SYSTEM_HIP") == "1":
+    log = logging.getLogger("scanspaceimageprocessor_amd")
+    if "torch" in sys.modules:
+        _hip_runtime_choice = "torch (imported before the library)"
+        log.debug("HIP runtime: torch's, already in the process")
+        return
+    if share is None:
+        share = os.environ.get("SCANSPACE_SHARE_TORCH_HIP") == "1"
+    if not share:
+        _hip_runtime_choice = "system"
+        log.debug("HIP runtime: the system's (import torch first, or set SCANSPACE_SHARE_TORCH_HIP=1, to share torch's)")
         return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
-    if spec is None or not spec.submodule_search_locations:
-        return
-    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(path):
+    path = None
+    if spec is not None and spec.submodule_search_locations:
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if path and os.path.exists(path):
         try:
             C.CDLL(path, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass  # the system runtime is used; importing torch later in this process may then fail
+            _hip_runtime_choice = f"torch (preloaded {path})"
+            log.debug("HIP runtime: preloaded %s", path)
+            return
+        except OSError as e:
+            log.warning("could not preload %s (%s): the system HIP runtime is used; importing torch later in this "
+                        "process may fail", path, e)
+    _hip_runtime_choice = "system"
 
 
-def load_library():
-    """Load libscanspace_hip.so (built in-tree by ``__graft_entry__.build()``) and type its symbols."""
+def hip_runtime_choice():
+    """"system", or "torch (...)": the HIP runtime ``load_library`` arranged for (None before the first load)."""
+    return _hip_runtime_choice
+
+
+def load_library(share_torch_hip=None):
+    """Load libscanspace_hip.so (built in-tree by ``__graft_entry__.build()``) and type its symbols.
+    ``share_torch_hip``: preload torch's bundled HIP runtime first (see ``_share_torch_hip_runtime``; None = only when
+    SCANSPACE_SHARE_TORCH_HIP=1).  Only the first call in a process loads anything."""
     global _lib
     with _lib_lock:
         if _lib is None:
@@ -179,7 +209,7 @@ def load_library():
                 raise ImportError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-            _share_torch_hip_runtime()
+            _share_torch_hip_runtime(share_torch_hip)
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

@@ -470,6 +470,21 @@ int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, cons
   return SS_OK;
 }
 
+// src_dev == dst_dev: every pixel is read once and written once by the same lane, which is safe for the pointwise
+// kernel with a float32 output.  Not for the tile kernel (halos), not for narrower outputs (the store of one lane
+// covers pixels other lanes still have to read), and not for chains whose recorded pixels are evaluated again from
+// the SOURCE by the float64 kernel: in place that source is already the float32 result.
+int check_in_place(ss_ctx* c, const ChainParams& P, int out_kind, const float* src_dev, const void* dst_dev) {
+  if ((const void*)src_dev != dst_dev) return SS_OK;
+  if (P.usm || out_bytes_per_px(out_kind) != 12)
+    return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
+  if (chain_needs_careful(P, out_kind))
+    return fail(c, SS_ERR_INVALID,
+                "in-place operation is not available for chains with a shadows/highlights stage: the pixels float32 "
+                "cannot follow are evaluated again from the source image, which an in-place run has overwritten");
+  return SS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -580,8 +595,9 @@ static int chain_run_two(ss_ctx* c, const ss_chain_desc* d, const float* src_dev
     return fail(c, SS_ERR_INVALID, "a chain on Lab data (lab_io) has no 8-bit second output: its values are not RGB");
   P.dst2 = (unsigned char*)dst2_dev;
   P.dst2_encoded = out_kind2 == SS_OUT_U8_SRGB ? 1 : 0;
-  if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
-    return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
+  c->last_risk_count = nullptr;  // (the workspace it points into may be reallocated below)
+  rc = check_in_place(c, P, d->out_kind, src_dev, dst_dev);
+  if (rc) return rc;
   ChainScratch S{c->usm_ticket, RiskMap{nullptr, nullptr, nullptr}};
   if (chain_needs_careful(P, d->out_kind)) {
     rc = context_scratch(c, P, d->batch, &S);
@@ -613,8 +629,9 @@ int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev,
   ChainParams P;
   rc = build_params(c, d, &P);
   if (rc) return rc;
-  if ((const void*)src_dev == dst_dev && (P.usm || out_bytes_per_px(d->out_kind) != 12))
-    return fail(c, SS_ERR_INVALID, "in-place operation needs a float32 output and no unsharp mask");
+  c->last_risk_count = nullptr;
+  rc = check_in_place(c, P, d->out_kind, src_dev, dst_dev);
+  if (rc) return rc;
   if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3)
     return fail(c, SS_ERR_UNSUPPORTED,
                 "an unsharp mask behind a %d-term colour correction needs a float32 staging image per image of the "
@@ -1164,10 +1181,20 @@ int ss_allgather_stats(ss_ctx* c, void* comm, int32_t rank, int32_t world, int64
                        float* all_dev) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!comm || !local_dev || !all_dev) return fail(c, SS_ERR_INVALID, "comm, local_dev and all_dev must not be NULL");
+  if (!comm || !all_dev) return fail(c, SS_ERR_INVALID, "comm and all_dev must not be NULL");
   if (world < 1 || rank < 0 || rank >= world || n_images < 0)
     return fail(c, SS_ERR_INVALID, "rank %d of %d, %lld images", rank, world, (long long)n_images);
   if (n_images == 0) return SS_OK;
+  {
+    // a rank whose shard is empty (fewer images than ranks) has nothing to send and may pass no buffer; it still
+    // has to take part in the collective, or the other ranks wait for it
+    int64_t my_first, my_count;
+    shard_of(n_images, rank, world, &my_first, &my_count);
+    if (!local_dev && my_count > 0)
+      return fail(c, SS_ERR_INVALID, "local_dev is NULL but rank %d of %d holds %lld of the %lld images", rank, world,
+                  (long long)my_count, (long long)n_images);
+    if (!local_dev) local_dev = all_dev;  // never read: this rank is the root of no broadcast
+  }
   const Rccl& R = rccl();
   if (!R.why.empty()) return fail(c, SS_ERR_UNSUPPORTED, "%s", R.why.c_str());
   ncclComm_t k = (ncclComm_t)comm;

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainParams P_arg, con
   constexpr int STAGE_WORDS = G == 1 ? 1 : 1024 * 3 * BYTES / 4;
   __shared__ uint32_t stage[STAGE_WORDS];
 
-  for (uint32_t base = blockIdx.x * CHUNK; base < n_groups; base += gridDim.x * CHUNK) {
+  // (base * G < n rather than base < n_groups: when the groups fill their last chunk exactly, the n % G pixels behind
+  // them still get a trip, which records them and stores their second output; their first output is stored below)
+  for (uint32_t base = blockIdx.x * CHUNK; base * G < n; base += gridDim.x * CHUNK) {
     const ChainParams& P = params_now();
     F3 in[4] = {};
 #pragma unroll

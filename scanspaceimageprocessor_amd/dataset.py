@@ -13,6 +13,25 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 
+def _torch():
+    """``import torch`` with the ordering rule of the two HIP runtimes checked first (``_lib._share_torch_hip_runtime``):
+    once the library has been loaded against the system runtime, a first import of torch in the same process brings a
+    second runtime that finds no GPU.  Said here, where it can still be explained."""
+    import sys
+
+    if "torch" not in sys.modules:
+        from . import _lib
+
+        if _lib.hip_runtime_choice() == "system":
+            raise ImportError(
+                "torch is being imported after libscanspace_hip.so was loaded against the system HIP runtime: two HIP "
+                "runtimes in one process.  Import torch before the first scanspaceimageprocessor_amd call, or set "
+                "SCANSPACE_SHARE_TORCH_HIP=1 (load_library(share_torch_hip=True)) so that the library shares torch's.")
+    import torch
+
+    return torch
+
+
 def shard_range(n_images: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous balanced shard ``(first, count)`` of ``n_images`` for ``rank`` of ``world``."""
     if world < 1 or not (0 <= rank < world) or n_images < 0:
@@ -29,7 +48,7 @@ def gather_brightness(local, n_images: int, group=None):
     RCCL) or on the CPU (backend gloo).  Uneven shards are padded to the largest shard for the
     collective and compacted afterwards.  With a single process the input is returned as is.
     """
-    import torch
+    torch = _torch()
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -64,7 +83,7 @@ class AbiGather:
         self.out = None
 
     def __call__(self, local, n_images: int):
-        import torch
+        torch = _torch()
 
         if self.out is None or self.out.numel() != n_images:
             self.out = torch.empty((n_images,), dtype=torch.float32, device=local.device)
@@ -77,13 +96,13 @@ class HipExposureOps:
     (``ss_exposure_stats``, ``ss_exposure_multipliers``) over torch CUDA tensors."""
 
     def __init__(self, ctx):
-        import torch
+        torch = _torch()
 
         self.ctx = ctx
         self.device = torch.device("cuda", ctx.device)
 
     def empty(self, count):
-        import torch
+        torch = _torch()
 
         return torch.empty((count,), dtype=torch.float32, device=self.device)
 
@@ -97,7 +116,7 @@ class HipExposureOps:
     def stream_scope(self):
         """Context manager that makes the context's stream torch's current stream: the collective must follow the
         statistics kernel and precede the multiplier kernel, whatever torch's current stream is."""
-        import torch
+        torch = _torch()
 
         return torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream, device=self.device))
 

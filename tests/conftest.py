@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Tests load the library and, in other files of the same process, torch: the library must share torch's bundled HIP
+# runtime (two runtimes in one process find no GPU), which it only does when asked.
+os.environ.setdefault("SCANSPACE_SHARE_TORCH_HIP", "1")
+
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 

@@ -41,7 +41,7 @@ def _worker(rank, world, port, n_images, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_images", [(2, 8), (2, 7), (3, 5)])
+@pytest.mark.parametrize("world,n_images", [(2, 8), (2, 7), (3, 5), (3, 2)])  # (3, 2): one rank holds no image
 def test_gather_and_multipliers_match_single_process(world, n_images):
     port = _free_port()
     with mp.Manager() as mgr:
@@ -99,7 +99,7 @@ def _normaliser_worker(rank, world, port, n_images, chart_index, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_images,chart_index", [(2, 8, None), (2, 7, 5), (3, 5, 0)])
+@pytest.mark.parametrize("world,n_images,chart_index", [(2, 8, None), (2, 7, 5), (3, 5, 0), (3, 2, 1)])
 def test_exposure_normaliser_class_over_gloo(world, n_images, chart_index):
     """The product's ExposureNormaliser itself (rank/offset arithmetic, statistics -> gather -> multipliers order,
     the world > 1 branch) on every rank of a gloo group; only the two compute steps are host stand-ins."""

@@ -98,3 +98,94 @@ def test_second_output_arguments_are_checked():
     finally:
         for x in (a, b, c):
             x.free()
+
+
+@pytest.mark.parametrize("shape,out", [((25, 41), "u16"),      # 1025 px: one pixel behind 512 full groups of two
+                                       ((1, 1), "u16"),        # fewer pixels than one group
+                                       ((13, 79), "u8_srgb"),  # 1027 px: three pixels behind 256 full groups of four
+                                       ((1, 3), "u8_srgb"),
+                                       ((32, 32), "u16"), ((25, 41), "f32")])
+@pytest.mark.parametrize("name", ["ccm", "sh"])
+def test_second_output_of_the_pixels_behind_the_last_full_group(shape, out, name):
+    """A lane stores 12 bytes = 2 (16-bit) or 4 (8-bit) pixels; when H * W leaves a remainder and the full groups fill
+    their last 1024-pixel chunk exactly, the remaining pixels get a trip of their own: their second output and their
+    place in the record of pixels to evaluate again must not depend on that."""
+    ctx = default_context()
+    kw = _chains()[name]
+    h, w = shape
+    b = 2
+    imgs = np.stack([inputs.linear_image(900 + i, h, w) for i in range(b)]).astype(np.float32)
+    src = DeviceBuffer.from_array(ctx, imgs)
+    dt = _lib.OUT_DTYPES[make_desc(h, w, b, out=out).out_kind]
+    one = DeviceBuffer(ctx, imgs.size * np.dtype(dt).itemsize)
+    two = DeviceBuffer.from_array(ctx, np.full(imgs.size, 0xA5, np.uint8))  # stale bytes must not survive
+    ref1 = DeviceBuffer(ctx, imgs.size * np.dtype(dt).itemsize)
+    ref2 = DeviceBuffer(ctx, imgs.size)
+    try:
+        ctx.chain_run2(make_desc(h, w, b, out=out, **kw), src.ptr, one.ptr, _lib.SS_OUT_U8_LINEAR, two.ptr)
+        ctx.chain_run(make_desc(h, w, b, out=out, **kw), src.ptr, ref1.ptr)
+        ctx.chain_run(make_desc(h, w, b, out="u8_linear", **kw), src.ptr, ref2.ptr)
+        ctx.sync()
+        got1, got2 = one.to_array(imgs.shape, dt), two.to_array(imgs.shape, np.uint8)
+        want1, want2 = ref1.to_array(imgs.shape, dt), ref2.to_array(imgs.shape, np.uint8)
+    finally:
+        for x in (src, one, two, ref1, ref2):
+            x.free()
+    assert np.array_equal(got1.view(np.uint8), want1.view(np.uint8))
+    assert np.array_equal(got2, want2), f"second output differs at {np.argwhere(got2 != want2)[:4].tolist()}"
+
+
+def test_recorded_pixels_behind_the_last_full_group_are_evaluated_again():
+    """The same tail pixels with an edit float32 cannot follow: they must reach the float64 kernel like any other
+    pixel.  As a batch of 1 x 1 images every pixel is such a tail pixel (16-bit output: groups of two); the same
+    pixels as one image give the count and the values to expect."""
+    ctx = default_context()
+    h, w = 160, 250
+    img = inputs.linear_image(41, h, w).astype(np.float32)
+    kw = dict(ccm=fit(M_T, M_R), gains=[1.0], sh=(0.5, -0.5, 7.0), final_clip=True)
+    src = DeviceBuffer.from_array(ctx, img)
+    whole, single = DeviceBuffer(ctx, img.size * 2), DeviceBuffer(ctx, img.size * 2)
+    try:
+        ctx.chain_run(make_desc(h, w, 1, out="u16", **kw), src.ptr, whole.ptr)
+        n_whole = ctx.chain_requeued()
+        ctx.chain_run(make_desc(1, 1, h * w, out="u16", **kw), src.ptr, single.ptr)
+        n_single = ctx.chain_requeued()
+        a, b = whole.to_array(img.shape, np.uint16), single.to_array(img.shape, np.uint16)
+    finally:
+        for x in (src, whole, single):
+            x.free()
+    assert n_whole > 0, "the case is meant to record pixels"
+    assert n_single == n_whole
+    assert np.array_equal(a, b)
+
+
+def test_in_place_rules():
+    """src == dst: fine for a float32 output of a chain without a Lab edit, refused wherever the result would depend
+    on the order lanes run in or on the source being intact for the float64 re-evaluation."""
+    ctx = default_context()
+    h, w = 40, 50
+    img = inputs.linear_image(3, h, w).astype(np.float32)[None]
+    lin3 = fit(M_T, M_R)
+    plain = dict(ccm=lin3, gains=[1.1], final_clip=True)
+    a = DeviceBuffer.from_array(ctx, img)
+    b = DeviceBuffer(ctx, img.nbytes)
+    try:
+        ctx.chain_run(make_desc(h, w, 1, out="f32_srgb", **plain), a.ptr, b.ptr)
+        ctx.chain_run(make_desc(h, w, 1, out="f32_srgb", **plain), a.ptr, a.ptr)
+        ctx.sync()
+        assert np.array_equal(a.to_array(img.shape, np.float32), b.to_array(img.shape, np.float32))
+        ctx.upload(a.ptr, img)
+        for bad in (dict(sh=(0.5, -0.5, 7.0), **plain), dict(usm=(20.0, 1.0, 0.0), **plain)):
+            for run in (ctx.chain_run, ctx.chain_run_static):
+                with pytest.raises(ScanSpaceError, match="in-place"):
+                    run(make_desc(h, w, 1, out="f32_srgb", **bad), a.ptr, a.ptr)
+        with pytest.raises(ScanSpaceError, match="in-place"):
+            ctx.chain_run(make_desc(h, w, 1, out="u16", **plain), a.ptr, a.ptr)
+        # an 8-bit output of a shadows/highlights chain is never re-evaluated, but is narrower than the input: refused too
+        with pytest.raises(ScanSpaceError, match="in-place"):
+            ctx.chain_run(make_desc(h, w, 1, out="u8_srgb", sh=(0.5, -0.5, 7.0), **plain), a.ptr, a.ptr)
+        ctx.sync()
+        assert np.array_equal(a.to_array(img.shape, np.float32), img), "a refused call must not touch the image"
+    finally:
+        a.free()
+        b.free()
