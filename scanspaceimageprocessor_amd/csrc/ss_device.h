@@ -219,6 +219,14 @@ __device__ __forceinline__ v2f fma_clip01(v2f a, float b, float c) {
   asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "s"(b2), "v"(c2));
   return r;
 }
+// clip(a * b + c, 0, 1), a and b per lane, c wave-uniform
+__device__ __forceinline__ float fma2_clip01(float a, float b, float c) { return clamp01(fmaf(a, b, c)); }
+__device__ __forceinline__ v2f fma2_clip01(v2f a, v2f b, float c) {
+  v2f r;
+  const v2f c2 = {c, c};
+  asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "s"(c2));
+  return r;
+}
 // colour.algebra.spow with p = 1/2, 1/3, 1/4: sign(x) * |x| ** p, exact zero at zero
 template <class V>
 __device__ __forceinline__ V sroot2(V x) { return vcopysign(hw_sqrt(vabs(x)), x); }
@@ -362,7 +370,10 @@ template <class V>
 struct RiskT {
   V mx;
   PxT<V> o;
+  bool any = true;  // wave-uniform: false = no pixel of this wave can have a large edit (mx was not formed)
 };
+__device__ __forceinline__ bool lane_above(float x, float lim) { return x > lim; }
+__device__ __forceinline__ bool lane_above(v2f x, float lim) { return x.x > lim || x.y > lim; }
 __device__ __forceinline__ bool risk_channel(float o, float lim) { return o > kRiskBelowZero && o < lim; }
 template <int OUT>
 __device__ __forceinline__ bool risk_big(float mx) {
@@ -432,25 +443,46 @@ __device__ __forceinline__ V finv_delta_any(V f, V d) {
   const V nm = sub_from_const_clip01(T, f), nm2 = sub_from_const_clip01(T, f2);
   const V dm = nm - nm2, dc = d - dm;
   const V c = f + nm, c2 = f2 + nm2;
-  return mad<V>(dm, 3.0f * T * T, dc * mad<V>(dc, dc, (c * c2) * 3.0f));
+  // dc (3 c c2 + dc^2) + 3 T^2 dm with dm = d - dc:  dc (3 c c2 - 3 T^2 + dc^2) + 3 T^2 d
+  // (below T: c = c2 = T and the bracket is dc^2 with dc = 0; on the cubic segment dc = d exactly)
+  return mad<V>(d, 3.0f * T * T, dc * mad<V>(dc, dc, mad<V>(c * c2, 3.0f, -3.0f * T * T)));
 }
 
-// linear + M_inv * (g(f + df) - g(f)): the edited pixel before _lab_to_rgb encodes and clips it
+// a + drift[I] x: nothing at all for the entry that is zero
+template <int I, class V>
+__device__ __forceinline__ V drift_mad(V x, V a) {
+  if constexpr (kLab.drift[I] == 0.0f) {
+    return a;
+  } else {
+    return mad<V>(kLab.drift[I], x, a);
+  }
+}
+
+// linear + M_inv * (g(f + df) - g(f)): the edited pixel before _lab_to_rgb encodes and clips it.
+// `same_d_floor` > 0: the caller guarantees dfx = dfy = dfz and 0 <= linear <= 1, so that f <= 1.0001 and
+// |g(f + d) - g(f)| <= 3 (1.0001 + |d|)^2 |d|: when no pixel of the wave has |d| above the floor, no edit of the
+// wave is large (see RiskCfg) and mx - two maxima per pixel - is not formed.
 template <class V>
 __device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy,
-                                                 const V dfz, RiskT<V>* risk = nullptr) {
+                                                 const V dfz, RiskT<V>* risk = nullptr, float same_d_floor = 0.0f) {
   // (a wave-uniform shortcut for "every pixel on the cubic segment" costs as much to decide as it saves)
   const V dx = finv_delta_any(f.fx, dfx), dy = finv_delta_any(f.fy, dfy), dz = finv_delta_any(f.fz, dfz);
   // the unedited part of the round trip: (I + E) . linear, E = the mismatch of the two IEC matrices
-  const V ur = mad<V>(kLab.drift[0], lin.r, mad<V>(kLab.drift[1], lin.g, mad<V>(kLab.drift[2], lin.b, lin.r)));
-  const V ug = mad<V>(kLab.drift[3], lin.r, mad<V>(kLab.drift[4], lin.g, mad<V>(kLab.drift[5], lin.b, lin.g)));
-  const V ub = mad<V>(kLab.drift[6], lin.r, mad<V>(kLab.drift[7], lin.g, mad<V>(kLab.drift[8], lin.b, lin.b)));
+  const V ur = drift_mad<0, V>(lin.r, drift_mad<1, V>(lin.g, drift_mad<2, V>(lin.b, lin.r)));
+  const V ug = drift_mad<3, V>(lin.r, drift_mad<4, V>(lin.g, drift_mad<5, V>(lin.b, lin.g)));
+  const V ub = drift_mad<6, V>(lin.r, drift_mad<7, V>(lin.g, drift_mad<8, V>(lin.b, lin.b)));
   PxT<V> o;
   o.r = mad<V>(kLab.inv[0], dx, mad<V>(kLab.inv[1], dy, mad<V>(kLab.inv[2], dz, ur)));
   o.g = mad<V>(kLab.inv[3], dx, mad<V>(kLab.inv[4], dy, mad<V>(kLab.inv[5], dz, ug)));
   o.b = mad<V>(kLab.inv[6], dx, mad<V>(kLab.inv[7], dy, mad<V>(kLab.inv[8], dz, ub)));
   if (risk) {
-    risk->mx = vmax3abs(dx, dy, dz);
+    if (same_d_floor > 0.0f) {
+      risk->any = __ballot(lane_above(vabs(dfy), same_d_floor)) != 0ull;
+      risk->mx = (V)(0.0f);
+      if (risk->any) risk->mx = vmax3abs(dx, dy, dz);
+    } else {
+      risk->mx = vmax3abs(dx, dy, dz);
+    }
     risk->o = o;
   }
   return o;
@@ -459,8 +491,8 @@ __device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V
 // clip(encode(.)) of it: what _lab_to_rgb returns for the edited pixel
 template <class V>
 __device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy, const V dfz,
-                                              const ChainParams& P, RiskT<V>* risk = nullptr) {
-  const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz, risk);
+                                              const ChainParams& P, RiskT<V>* risk = nullptr, float same_d_floor = 0.0f) {
+  const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz, risk, same_d_floor);
   return PxT<V>{srgb_encode_clip(o.r), srgb_encode_clip(o.g), srgb_encode_clip(o.b)};
 }
 
@@ -849,9 +881,11 @@ __device__ __forceinline__ LabT<V> usm_on_lab(const V Ln, const V a, const V b, 
 
 // The same edit on RGB data: `lin` = decoded (linear) pixel, Ln = L/100 of it, Lb = blurred Ln.
 // Returns what _lab_to_rgb gives for the sharpened pixel (sRGB-encoded, clipped).
-template <bool PLAIN = false, class V = float>
+// CHROMA: 1 / 0 = the chroma boost (amount > 30) is known to be on / off, -1 = read P.usm_chroma.
+// `risk_floor` (with PLAIN and CHROMA == 0 only): RiskCfg<OUT>::MIN_MX of the caller's output, 0 = none.
+template <bool PLAIN = false, class V = float, int CHROMA = -1>
 __device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const V Lb, const ChainParams& P,
-                                             RiskT<V>* risk = nullptr) {
+                                             RiskT<V>* risk = nullptr, float risk_floor = 0.0f) {
   LabFT<V> f;
   f.fy = mad<V>(Ln, 100.0f / 116.0f, 16.0f / 116.0f);
   f.fx = lab_f(mad<V>(kLab.fwd[0], lin.r, mad<V>(kLab.fwd[1], lin.g, lin.b * kLab.fwd[2])));
@@ -865,17 +899,22 @@ __device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const
   // (Ln is in [0, 1], so both are >= 0 and min(., 1) is a clip to [0, 1]: the clamp modifier of the instruction)
   const V hm = fma_clip01(Ln - 0.9f, -10.0f, 1.0f);
   const V sm = mul_clip01(Ln, 10.0f);
-  const V ad = vmax(hm * sm, (V)(0.1f));
+  // clip(hm sm, 0.1, 1) as 0.1 + clip(hm sm - 0.1, 0, 1): a max costs 1.8 times an add on this GPU
+  const V ad = fma2_clip01(hm, sm, -0.1f) + 0.1f;
   // clip(Ln + um * amount * ad, 0, 1) - Ln, exactly; L = 100 Ln = 116 fy - 16
   const V dfy = med3((um * P.usm_amount_scaled) * ad, -Ln, 1.0f - Ln) * (100.0f / 116.0f);
   V dfx = dfy, dfz = dfy;
-  if (P.usm_chroma) {
+  const bool chroma = CHROMA < 0 ? P.usm_chroma != 0 : CHROMA != 0;
+  if (chroma) {
     const V boost = mad<V>(vabs(um), P.usm_chroma_k, 1.0f);
     const V a = (f.fx - f.fy) * 500.0f, b = (f.fy - f.fz) * 200.0f;
     dfx = mad<V>(clampf(a * boost, -127.0f, 127.0f) - a, 1.0f / 500.0f, dfy);
     dfz = mad<V>(clampf(b * boost, -127.0f, 127.0f) - b, -1.0f / 200.0f, dfy);
   }
-  return shifted_rgb(lin, f, dfx, dfy, dfz, P, risk);
+  // one d for X, Y and Z and a pixel in [0, 1]: |d| <= floor / 4 keeps every |g(f + d) - g(f)| below the floor
+  // (3 (1.0001 + d)^2 d <= 0.91 floor for floor <= 0.4)
+  const float same_d_floor = (PLAIN && CHROMA == 0) ? risk_floor * 0.25f : 0.0f;
+  return shifted_rgb(lin, f, dfx, dfy, dfz, P, risk, same_d_floor);
 }
 
 // ---- stages 6-7: final clip, encoding, quantisation -------------------------------------------
@@ -893,6 +932,19 @@ __device__ __forceinline__ PxT<V> finish(PxT<V> p, const ChainParams& P) {
     p.b = srgb_encode(p.b);
   }
   return p;
+}
+
+// Output encoding of a pixel in [0, 1] for the 16-bit quantiser, scaled: 65535 encode(x), the factor folded into the
+// curve's constants (one rounding where the product behind the curve has two).  The caller truncates.
+template <class V>
+__device__ __forceinline__ V srgb_encode_scaled16(V L) {
+  const V hi = mad<V>(hw_exp2(hw_log2(L) * (1.0f / 2.4f)), (float)(1.055 * 65535.0), (float)(-0.055 * 65535.0));
+  const V lo = L * (float)(12.92 * 65535.0);
+  return L <= (V)(0.0031308f) ? lo : hi;
+}
+template <class V>
+__device__ __forceinline__ PxT<V> finish_scaled16(const PxT<V> p) {
+  return PxT<V>{srgb_encode_scaled16(p.r), srgb_encode_scaled16(p.g), srgb_encode_scaled16(p.b)};
 }
 
 // np.uint16(np.clip(x*65535, 0, 65535)) / np.uint8(np.clip(x*255, 0, 255)): truncation toward zero

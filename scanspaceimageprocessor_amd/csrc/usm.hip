@@ -44,10 +44,11 @@ constexpr int USM_WAVES_PER_SIMD = 2 * USM_NT / 256;  // two workgroups per CU
 #endif
 
 // UNIT: the values are known to lie in [0, 1] (no clamp needed before the truncating conversion)
-template <int OUT, bool UNIT>
+// SCALED (16-bit output): the values are the codes themselves, 0 ... 65535 with their fraction (finish_scaled16)
+template <int OUT, bool UNIT, bool SCALED = false>
 __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int y, int x, const Px o0, const Px o1) {
   if (y >= H || x >= W) return;
-  auto q16 = [](float v) -> uint32_t { return UNIT ? quant16_unit(v) : quant16(v); };
+  auto q16 = [](float v) -> uint32_t { return SCALED ? (uint32_t)v : (UNIT ? quant16_unit(v) : quant16(v)); };
   auto q8 = [](float v) -> uint32_t { return UNIT ? quant8_unit(v) : quant8(v); };
   const bool two = x + 1 < W;
   const size_t px = (size_t)y * W + x;
@@ -90,9 +91,9 @@ __device__ __forceinline__ void usm_store_pair(void* dst_img, int W, int H, int 
 // The same for a pair that is known to lie inside the image with its 12-byte slot 4-byte aligned (a tile that the
 // image covers whole, in an image of even width): no bounds tests, no alignment test, a 32-bit byte offset on the
 // image's base address (an image has at most 2^28 pixels).
-template <int OUT, bool UNIT>
+template <int OUT, bool UNIT, bool SCALED = false>
 __device__ __forceinline__ void usm_store_pair_inside(void* dst_img, uint32_t byte_offset, const Px o0, const Px o1) {
-  auto q16 = [](float v) -> uint32_t { return UNIT ? quant16_unit(v) : quant16(v); };
+  auto q16 = [](float v) -> uint32_t { return SCALED ? (uint32_t)v : (UNIT ? quant16_unit(v) : quant16(v)); };
   auto q8 = [](float v) -> uint32_t { return UNIT ? quant8_unit(v) : quant8(v); };
   char* at = reinterpret_cast<char*>(dst_img) + byte_offset;
   if constexpr (OUT == SS_OUT_F32_LINEAR || OUT == SS_OUT_F32_SRGB) {
@@ -118,6 +119,7 @@ __device__ __forceinline__ void usm_store_pair_inside(void* dst_img, uint32_t by
 
 // R_T : compile-time blur radius (3 <-> sigma 1, 6 <-> sigma 2), 0 = runtime radius P.usm_r.
 // CCMC: CCM_LIN3 for the reference's 3-term correction, CCM_NONE for chains without one.
+// CHROMA: 0 / 1 = the launcher knows the chroma boost (amount > 30) to be off / on, -1 = P.usm_chroma decides.
 //
 // Strip walk: the tile grid of every image is cut into vertical segments of `seg_tiles` tiles, one tile
 // wide.  A workgroup walks a segment top to bottom, then takes the next free segment off a device-side
@@ -140,7 +142,7 @@ extern "C" int ss_debug_usm_trace(void* out) {
 }
 #endif
 
-template <int R_T, int CCMC, int OUT, bool PLAIN>
+template <int R_T, int CCMC, int OUT, bool PLAIN, int CHROMA = -1>
 __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const ChainParams P, const StripWalk T_arg,
                                                      const float* __restrict__ src, void* __restrict__ dst) {
 #ifdef SS_USM_WALK_IN_REGISTERS
@@ -439,6 +441,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
       // one pixel pair at a time: everything after the blur
       // (`inside_at`: byte offset of the pair's slot in the output image, used for tiles the image covers whole)
       constexpr uint32_t PX_BYTES = 3u * OutTraits<OUT>::BYTES;
+      // 16-bit output of the plain chain: the quantiser's factor 65535 is folded into the constants of the output encoding
+      constexpr bool SCALED16 = PLAIN && OUT == SS_OUT_U16_SRGB;
       auto slot_at = [&](int ly, int px) -> uint32_t {
         return ((uint32_t)(y0 + ly) * (uint32_t)W + (uint32_t)(x0 + px)) * PX_BYTES;
       };
@@ -457,7 +461,8 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
           const Lab2 q = usm_on_lab<PLAIN, v2f>(Ln, v2f{c1.x, c1.y}, v2f{c2.x, c2.y}, blur, P);
           o = Px2{q.L, q.a, q.b};
         } else if constexpr (PLAIN) {
-          o = usm_on_rgb<PLAIN, v2f>(Px2{v2f{c0.x, c0.y}, v2f{c1.x, c1.y}, v2f{c2.x, c2.y}}, Ln, blur, P, &risk);
+          o = usm_on_rgb<PLAIN, v2f, CHROMA>(Px2{v2f{c0.x, c0.y}, v2f{c1.x, c1.y}, v2f{c2.x, c2.y}}, Ln, blur, P, &risk,
+                                             RiskCfg<OUT>::ENABLED ? RiskCfg<OUT>::MIN_MX : 0.0f);
         } else {
           // phase 1 hands the size of a shadows/highlights edit over in the signs of the channel values (which
           // that stage has clipped to [0, 1]; without the stage a value may be negative in its own right)
@@ -481,12 +486,16 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
           }
         }
         // the sharpened pixel is in [0,1]; the LAB branch has no final clip: either way the clip stage is a no-op here
-        o = finish<OUT, true, v2f>(o, P);
+        if constexpr (SCALED16)
+          o = finish_scaled16<v2f>(o);
+        else
+          o = finish<OUT, true, v2f>(o, P);
         // Pixels whose Lab edits float32 cannot follow (see RiskCfg) are recorded for the float64 kernel, their
         // blurred lightness waiting in the first four bytes of their own output slot.  Almost never taken.
         if constexpr (RiskCfg<OUT>::ENABLED) {
           const bool big0 = risk_big<OUT>(risk.mx.x), big1 = risk_big<OUT>(risk.mx.y);
-          if (__ballot(big0 || big1) != 0ull) {        // a scalar branch: the whole wave skips it
+          // (risk.any: wave-uniform, false when the edit's own pre-test has ruled a large edit out for the whole wave)
+          if (risk.any && __ballot(big0 || big1) != 0ull) {  // a scalar branch: the whole wave skips it
             const ChainParams& Pr = kernarg_params();  // (nothing this branch needs stays in registers outside it)
             const int Wr = Pr.width, Hr = Pr.height;
             const int gy = y0 + ly, gx = x0 + px;
@@ -496,6 +505,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
             auto stash = [](float Lb, float r, float g) -> float2 {
               if constexpr (OUT == SS_OUT_U16_SRGB) {  // two 16-bit codes
                 const uint32_t u = __float_as_uint(Lb);
+                if constexpr (SCALED16) return float2{(float)(u & 0xFFFFu) + 0.5f, (float)(u >> 16) + 0.5f};
                 return float2{((float)(u & 0xFFFFu) + 0.5f) * (1.0f / 65535.0f), ((float)(u >> 16) + 0.5f) * (1.0f / 65535.0f)};
               } else {
                 return float2{Lb, g};
@@ -521,9 +531,9 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         asm volatile("" ::"v"(o.r.x), "v"(o.r.y), "v"(o.g.x), "v"(o.g.y), "v"(o.b.x), "v"(o.b.y));
 #else
         if (inside)
-          usm_store_pair_inside<OUT, PLAIN>(d, inside_at, px_lo(o), px_hi(o));
+          usm_store_pair_inside<OUT, PLAIN, SCALED16>(d, inside_at, px_lo(o), px_hi(o));
         else
-          usm_store_pair<OUT, PLAIN>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
+          usm_store_pair<OUT, PLAIN, SCALED16>(d, W, H, y0 + ly, x0 + px, px_lo(o), px_hi(o));
 #endif
       };
       if constexpr (MFMA) {
@@ -673,9 +683,9 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         // the size of a shadows/highlights edit travels to phase 3 in the signs of the (non-negative) values
         if (!PLAIN && P.sh) {
           const uint32_t l = risk_level(risk.mx);
-          return Slot{fmaf(fy, 116.0f, -16.0f) * 0.01f, F3{risk_tag(r, l, 0), risk_tag(g, l, 1), risk_tag(b, l, 2)}};
+          return Slot{fmaf(fy, 1.16f, -0.16f), F3{risk_tag(r, l, 0), risk_tag(g, l, 1), risk_tag(b, l, 2)}};
         }
-        return Slot{fmaf(fy, 116.0f, -16.0f) * 0.01f, F3{r, g, b}};
+        return Slot{fmaf(fy, 1.16f, -0.16f), F3{r, g, b}};  // Ln = (116 fy - 16) / 100
 #endif
       };
       // two slots in lock step (packed arithmetic)
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(USM_NT, USM_WAVES_PER_SIMD) void usm_kernel(const C
         }
         const v2f r = p.r, g = p.g, b = p.b;
         const v2f fy = lab_f(mad<v2f>(kLab.fwd[3], r, mad<v2f>(kLab.fwd[4], g, b * kLab.fwd[5])));
-        const v2f Ln = mad<v2f>(fy, 116.0f, -16.0f) * 0.01f;
+        const v2f Ln = mad<v2f>(fy, 1.16f, -0.16f);
         if (!PLAIN && P.sh) {
           const uint32_t la = risk_level(risk.mx.x), lb = risk_level(risk.mx.y);
           qa = Slot{Ln.x, F3{risk_tag(r.x, la, 0), risk_tag(g.x, la, 1), risk_tag(b.x, la, 2)}};
@@ -813,38 +823,43 @@ static size_t usm_lds_bytes(int r) {
   return (size_t)(PH * PW + PH * USM_TW + USM_TH * USM_TW * 3) * sizeof(float);
 }
 
-template <int R_T, int CCMC, int OUT, bool PLAIN>
+template <int R_T, int CCMC, int OUT, bool PLAIN, int CHROMA = -1>
 static hipError_t launch_usm_one(const ChainParams& P, int batch, const float* src, void* dst, uint32_t* ticket,
                                   hipStream_t st) {
-  const size_t lds = usm_lds_bytes(P.usm_r);
-  auto kern = usm_kernel<R_T, CCMC, OUT, PLAIN>;
-  if (lds > 64 * 1024) {  // sticky per device and kernel; cheap enough to repeat
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+  if constexpr (PLAIN && R_T != 0 && CHROMA < 0) {  // the plain chains know their chroma branch at compile time
+    return P.usm_chroma ? launch_usm_one<R_T, CCMC, OUT, PLAIN, 1>(P, batch, src, dst, ticket, st)
+                        : launch_usm_one<R_T, CCMC, OUT, PLAIN, 0>(P, batch, src, dst, ticket, st);
+  } else {
+    const size_t lds = usm_lds_bytes(P.usm_r);
+    auto kern = usm_kernel<R_T, CCMC, OUT, PLAIN, CHROMA>;
+    if (lds > 64 * 1024) {  // sticky per device and kernel; cheap enough to repeat
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    StripWalk T;
+    T.tiles_x = (P.width + USM_TW - 1) / USM_TW;
+    T.tiles_y = (P.height + USM_TH - 1) / USM_TH;
+    int64_t cap = (int64_t)256 * usm_wg_per_cu();  // persistent workgroups
+    if (cap > usm_max_wg()) cap = usm_max_wg();
+    // segment length: long enough that the first tile's extra halo rows are noise, short enough that the
+    // workgroups finish close together
+    int seg = usm_seg_tiles();
+    if (seg > T.tiles_y) seg = T.tiles_y;
+    if (R_T == 0 || ccm_needs_table<CCMC>) seg = 1;  // only the fast path hands rows from tile to tile
+    T.seg_tiles = seg;
+    T.segs_y = (T.tiles_y + seg - 1) / seg;
+    const int64_t n_segments = (int64_t)T.tiles_x * T.segs_y * batch;
+    if (n_segments > INT32_MAX) return hipErrorInvalidValue;
+    T.n_segments = (uint32_t)n_segments;
+    T.chunk = (T.n_segments + 7) / 8;
+    T.ticket = ticket;
+    const unsigned blocks = (unsigned)(n_segments < cap ? n_segments : cap);
+    hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ticket), 0, 8, st);
+    if (me != hipSuccess) return me;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(USM_NT), lds, st, P, T, src, dst);
+    return hipGetLastError();
   }
-  StripWalk T;
-  T.tiles_x = (P.width + USM_TW - 1) / USM_TW;
-  T.tiles_y = (P.height + USM_TH - 1) / USM_TH;
-  int64_t cap = (int64_t)256 * usm_wg_per_cu();  // persistent workgroups
-  if (cap > usm_max_wg()) cap = usm_max_wg();
-  // segment length: long enough that the first tile's extra halo rows are noise, short enough that the
-  // workgroups finish close together
-  int seg = usm_seg_tiles();
-  if (seg > T.tiles_y) seg = T.tiles_y;
-  if (R_T == 0 || ccm_needs_table<CCMC>) seg = 1;  // only the fast path hands rows from tile to tile
-  T.seg_tiles = seg;
-  T.segs_y = (T.tiles_y + seg - 1) / seg;
-  const int64_t n_segments = (int64_t)T.tiles_x * T.segs_y * batch;
-  if (n_segments > INT32_MAX) return hipErrorInvalidValue;
-  T.n_segments = (uint32_t)n_segments;
-  T.chunk = (T.n_segments + 7) / 8;
-  T.ticket = ticket;
-  const unsigned blocks = (unsigned)(n_segments < cap ? n_segments : cap);
-  hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ticket), 0, 8, st);
-  if (me != hipSuccess) return me;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(USM_NT), lds, st, P, T, src, dst);
-  return hipGetLastError();
 }
 
 template <int R_T, int CCMC, bool PLAIN>
