@@ -46,8 +46,29 @@ ALGO_BYTES_PER_PX = 18.0  # 12 in (float32 RGB) + 6 out (uint16 RGB)
 # inside this process; they come from the rocprofv3 PMC passes summarised in this file (made by tools/pmc_summary.py
 # from the passes' CSVs, committed beside them), which the bench line names together with its SHA-256.  No file, no
 # figure: nothing is hard-coded.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_usm_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_usm_pmc.json")
 N_SIMD = 1024
+# Issue cost of a wave-instruction on one SIMD in cycles, by class, measured on this GPU with four waves per SIMD
+# (tools/micro/valu_rate3.hip; ns there, divided by the 2.05 GHz the chip ran at): a plain float32 / integer operation
+# goes through the 32-lane float pipe in 2 cycles, a packed one (two results) in 4, compares / selects / min / max /
+# med3 / conversions in about 3.6, 64-bit integer multiply-adds in 8, v_exp_f32 / v_log_f32 in 6.9.
+VALU_CYCLES = {"plain": 2.05, "packed_extra": 2.05, "slow": 3.6, "int64": 8.0, "trans": 6.9}
+
+
+def priced_valu_cycles(pmc):
+    """Vector-ALU cycles per 64 pixels the kernel's dynamic instruction mix costs at the prices above (None without
+    the mix pass).  Classes as the counters give them: float add / mul / fma, transcendental, 32- and 64-bit integer,
+    conversions, and the rest (compares, selects, min / max / med3, moves, lane reads), priced as the slow class.
+    A packed instruction counts once among add / mul / fma and costs twice: the flops counter gives
+    packed add + packed mul + 2 packed fma; the same packed share is assumed for the three."""
+    m = pmc.get("valu_mix")
+    if not m:
+        return None
+    c = VALU_CYCLES
+    floats = m["add_f32"] + m["mul_f32"] + m["fma_f32"]
+    packed = max(m.get("packed_extra_flops", 0.0), 0.0) * floats / (m["add_f32"] + m["mul_f32"] + 2.0 * m["fma_f32"])
+    return ((floats + m["int32"]) * c["plain"] + packed * c["packed_extra"] + m["trans_f32"] * c["trans"] +
+            m["int64"] * c["int64"] + (m["cvt"] + m["other"]) * c["slow"])
 
 
 def pmc_summary():
@@ -469,13 +490,23 @@ def main():
             roof.update({
                 # HBM bytes per launch from the counter passes (FETCH_SIZE doubled as gfx950 needs + WRITE_SIZE)
                 "traffic": round((pmc["fetch_bytes_per_px"] + pmc["write_bytes_per_px"]) * px_per_launch),
-                # vector-ALU roofline: instructions issued per second against one wave-instruction per SIMD per 4
-                # cycles (transcendental ones take two such slots)
                 "valu_instructions_per_px": pmc["valu_per_px"], "valu_trans_per_px": pmc["trans_per_px"],
-                "valu_frac": round((pmc["valu_per_px"] + pmc["trans_per_px"]) * px_per_s / (N_SIMD * clock_hz / 4 * 64), 4),
                 "valu_busy_profiled": pmc["valu_busy"], "clock_ghz_profiled": pmc["clock_ghz"],
                 "pmc_file": os.path.relpath(PMC_SUMMARY, ROOT), "pmc_sha256": pmc_sha,
             })
+            priced = priced_valu_cycles(pmc)
+            if priced is not None:
+                # vector-ALU roofline: the cycles the instruction mix costs, class by class, against the cycles a SIMD
+                # had per 64 pixels in this run (kernel time x the profiled clock / the wave-instructions' worth of
+                # pixels per SIMD); the rest of the time the vector unit had nothing it could issue
+                cycles_per_64px = kernel_ms * 1e-3 * clock_hz / (px_per_launch / 64.0 / N_SIMD)
+                roof.update({"valu_mix_per_px": pmc["valu_mix"], "valu_cycle_prices": VALU_CYCLES,
+                             "valu_priced_cycles_per_64px": round(priced, 1),
+                             "valu_cycles_per_64px": round(cycles_per_64px, 1),
+                             "valu_frac": round(priced / cycles_per_64px, 4),
+                             "valu_stall_frac": round(1.0 - priced / cycles_per_64px, 4),
+                             "wait_any_share_profiled": pmc.get("wait_any_share"),
+                             "wait_issue_share_profiled": pmc.get("wait_issue_share")})
         line["roofline"] = roof
         if world == 1 and not args.no_others and not config5:
             line["others"] = others()

@@ -369,6 +369,10 @@ int check_ctx(ss_ctx* c) {
   if (!c) return fail(nullptr, SS_ERR_INVALID, "context is NULL");
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(c, SS_ERR_HIP, "hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(e));
+  // The launchers read hipGetLastError() behind their kernel launches; that value is per thread and sticky, so an
+  // error some earlier, unrelated call of the host left behind (a refused allocation, an invalidated capture) would
+  // be reported as this call's launch failure.  It is taken off here.
+  (void)hipGetLastError();
   return SS_OK;
 }
 
