@@ -48,7 +48,7 @@ def expand_swatches(M, method="Cheung 2004", terms=3, degree=1):
             19: base + pairs + squares + rgb + mixed3 + mixed3b + cubes,
             20: base + pairs + squares + rgb + mixed3 + mixed3b + cubes + [one],
             22: base + pairs + squares + rgb + mixed3 + mixed3b + cubes
-            + [R * R * G * B, R * G * G * B, R * G * B * B],
+            + [R ** 2 * G * B, R * G ** 2 * B, R * G * B ** 2],
         }
         cols = table[terms]
     elif method == "Finlayson 2015":
@@ -58,12 +58,14 @@ def expand_swatches(M, method="Cheung 2004", terms=3, degree=1):
         if degree >= 2:
             cols += [_sroot(R * G, 2), _sroot(G * B, 2), _sroot(R * B, 2)]
         if degree >= 3:
-            cols += [_sroot(R * G * G, 3), _sroot(G * B * B, 3), _sroot(R * B * B, 3),
-                     _sroot(G * R * R, 3), _sroot(B * G * G, 3), _sroot(B * R * R, 3), _sroot(R * G * B, 3)]
+            # (the products in colour-science's order, squares first: with coefficients of 10^5 on an ill-conditioned
+            # fit, a last-bit difference in a swatch's term shows in the fitted matrix)
+            cols += [_sroot(R * G ** 2, 3), _sroot(G * B ** 2, 3), _sroot(R * B ** 2, 3),
+                     _sroot(G * R ** 2, 3), _sroot(B * G ** 2, 3), _sroot(B * R ** 2, 3), _sroot(R * G * B, 3)]
         if degree >= 4:
             cols += [_sroot(R ** 3 * G, 4), _sroot(R ** 3 * B, 4), _sroot(G ** 3 * R, 4), _sroot(G ** 3 * B, 4),
-                     _sroot(B ** 3 * R, 4), _sroot(B ** 3 * G, 4), _sroot(R * R * G * B, 4),
-                     _sroot(G * G * R * B, 4), _sroot(B * B * R * G, 4)]
+                     _sroot(B ** 3 * R, 4), _sroot(B ** 3 * G, 4), _sroot(R ** 2 * G * B, 4),
+                     _sroot(G ** 2 * R * B, 4), _sroot(B ** 2 * R * G, 4)]
     else:
         raise ValueError(f"unsupported colour correction method {method!r} (hot path: 'Cheung 2004', 'Finlayson 2015')")
     return np.stack(cols, axis=-1)

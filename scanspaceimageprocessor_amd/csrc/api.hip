@@ -438,9 +438,44 @@ size_t chain_stage_bytes() {
   return x > 0 ? (size_t)x : kChainStageBytes;
 }
 
-int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, const float* src_dev, void* dst_dev,
-                   const ChainScratch& S) {
+// Colour corrections whose coefficient table float32 cannot carry take the dense float64 pass (ccm_f64_kernel): with
+// the inputs in [0, 1] no term exceeds 1, so the sum of |coefficient x term| of an output channel is at most
+// C = sum over the terms of the largest |coefficient| of the term, and float32 keeps the channel to ~4e-7 C.  Held
+// against a third of the 1e-5 the result is compared at: C > 8.  (Fits of up to ~20 polynomial terms on 24 swatches stay
+// well below that; 22 terms and the root-polynomials of degree 3 and 4 have coefficients of 10 ... 10^5.)
+bool ccm_needs_f64(const ChainParams& P) {
+  if (P.ccm_kind == SS_CCM_NONE || P.ccm_terms <= 3) return false;
+  static const bool never = [] {  // SS_CCM_F64=0: a debugging aid (float32 throughout)
+    const char* v = getenv("SS_CCM_F64");
+    return v && v[0] == '0';
+  }();
+  if (never) return false;
+  double bound = 0.0;
+  for (int t = 0; t < P.ccm_terms; ++t) {
+    double m = 0.0;
+    for (int ch = 0; ch < 3; ++ch) m = fmax(m, fabs((double)P.ccm_full[t][ch] + (double)P.ccm_lo[t][ch]));
+    bound += m;
+  }
+  return 4.0e-7 * bound > 1.0e-5 / 3.0;
+}
+
+// nothing behind stages 1-2: their float32 result is the call's output
+bool chain_ends_behind_ccm(const ChainParams& P, int out_kind) {
+  return !P.usm && !P.sh && P.n_gain == 0 && !P.final_clip && !P.lab_io && out_kind == SS_OUT_F32_LINEAR && !P.dst2;
+}
+
+// Two launches per group of images through a float32 staging image: {negative inversion, colour correction}, then
+// everything behind them from the staged pixels.  Used for an unsharp mask behind a colour correction of more than 3
+// terms, and for every chain whose colour correction takes the float64 pass.
+int run_staged(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, const float* src_dev, void* dst_dev,
+               const ChainScratch& S) {
+  const bool dense = ccm_needs_f64(P);
   const size_t image_bytes = (size_t)P.n_px * 3 * sizeof(float);
+  if (dense && chain_ends_behind_ccm(P, d->out_kind)) {
+    const hipError_t e = launch_ccm_f64(P, d->batch, src_dev, (float*)dst_dev, c->stream);
+    if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return SS_OK;
+  }
   const size_t by_size = chain_stage_bytes() / image_bytes;
   int group = by_size > (size_t)d->batch ? d->batch : (int)by_size;
   if (group < 1) group = 1;
@@ -465,13 +500,22 @@ int run_staged_usm(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, cons
     if (B.gain0_dev) B.gain0_dev += first;
     A.dst2 = nullptr;  // the second output is made where the first is
     if (B.dst2) B.dst2 += (size_t)first * P.n_px * 3;
-    rc = launch_chain_and_careful(c, A, n, SS_OUT_F32_LINEAR, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, S);
-    if (rc) return rc;
+    if (dense) {
+      const hipError_t e = launch_ccm_f64(A, n, src_dev + (size_t)first * P.n_px * 3, (float*)c->ws_stage, c->stream);
+      if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    } else {
+      rc = launch_chain_and_careful(c, A, n, SS_OUT_F32_LINEAR, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, S);
+      if (rc) return rc;
+    }
     rc = launch_chain_and_careful(c, B, n, d->out_kind, (const float*)c->ws_stage,
                                   (char*)dst_dev + (size_t)first * out_image_bytes, S);
     if (rc) return rc;
   }
   return SS_OK;
+}
+
+bool chain_is_staged(const ChainParams& P) {
+  return (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3) || ccm_needs_f64(P);
 }
 
 // src_dev == dst_dev: every pixel is read once and written once by the same lane, which is safe for the pointwise
@@ -607,7 +651,7 @@ static int chain_run_two(ss_ctx* c, const ss_chain_desc* d, const float* src_dev
     rc = context_scratch(c, P, d->batch, &S);
     if (rc) return rc;
   }
-  if (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms != 3) return run_staged_usm(c, d, P, src_dev, dst_dev, S);
+  if (chain_is_staged(P)) return run_staged(c, d, P, src_dev, dst_dev, S);
   return launch_chain_and_careful(c, P, d->batch, d->out_kind, src_dev, dst_dev, S);
 }
 
@@ -641,6 +685,16 @@ int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev,
                 "an unsharp mask behind a %d-term colour correction needs a float32 staging image per image of the "
                 "batch, which the static scratch of ss_chain_run_static does not hold: use ss_chain_run",
                 P.ccm_terms);
+  if (ccm_needs_f64(P)) {
+    if (!chain_ends_behind_ccm(P, d->out_kind))
+      return fail(c, SS_ERR_UNSUPPORTED,
+                  "this %d-term colour correction is evaluated in float64 into a float32 staging image per image of "
+                  "the batch, which the static scratch of ss_chain_run_static does not hold: use ss_chain_run",
+                  P.ccm_terms);
+    const hipError_t e = launch_ccm_f64(P, d->batch, src_dev, (float*)dst_dev, c->stream);
+    if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return SS_OK;
+  }
   if (P.usm) {
     // the work queue's counters are 32-bit tickets over the segments of the whole batch
     const int64_t tiles = (int64_t)((d->width + 127) / 128) * ((d->height + 23) / 24) * d->batch;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void unpack_u16_kernel(const uint16_t* __restr
 hipError_t launch_unpack_u16(const uint16_t* src, float* dst, uint64_t n, hipStream_t st) {
   uint64_t blocks = (n / 8 + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 16384) blocks = 16384;
+  if (blocks > (1u << 22)) blocks = 1u << 22;  // (one trip per workgroup streams best)
   hipLaunchKernelGGL(unpack_u16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
   return hipGetLastError();
 }
@@ -266,6 +266,80 @@ hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const flo
   if (P.ccm_terms <= 8) return launch_chain_sh<CCM_SMALL>(P, batch, out_kind, src, dst, st);
   if (P.ccm_kind == SS_CCM_CHEUNG) return launch_chain_sh<CCM_CHEUNG>(P, batch, out_kind, src, dst, st);
   return launch_chain_sh<CCM_ROOT>(P, batch, out_kind, src, dst, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense float64 colour correction (stages 1-2 of every pixel), for coefficient tables float32 cannot carry
+// ------------------------------------------------------------------------------------------------
+
+// A fit with nearly as many terms as swatches (22 terms, root-polynomials of degree 3 and 4 on 24 swatches) has
+// coefficients of size 10 ... 10^5 whose products with the terms cancel to a pixel of size 1: float32 keeps such a
+// sum to ~4e-7 of the sum of |coefficient x term|, several times the 1e-5 the result is held to.  The reference
+// evaluates it in float64 (colour_correction converts its input first); so does this pass: negative inversion in
+// float32 as the reference does it, expansion and sum in float64 with the coefficients' float64 values
+// (ccm_full + ccm_lo), the result rounded to float32 (unclipped linear RGB) for the stages behind it.
+// One trip of 1024 pixels per workgroup, lane t taking pixels t, t + 256, ... like the pointwise chain.
+// (KIND, T: the expansion, compile-time so that the terms live in registers)
+template <int KIND, int T>
+__global__ __launch_bounds__(256) void ccm_f64_kernel(const ChainParams P, const float* __restrict__ src,
+                                                      float* __restrict__ dst) {
+  __shared__ double coef[T][3];
+  for (int i = threadIdx.x; i < T * 3; i += 256) {
+    const int t = i / 3, ch = i - t * 3;
+    coef[t][ch] = (double)P.ccm_full[t][ch] + (double)P.ccm_lo[t][ch];
+  }
+  __syncthreads();
+  const int img = blockIdx.y;
+  const ImgParams ip = load_img_params(P, img);
+  const uint32_t n = (uint32_t)P.n_px;
+  const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * n * 3);
+  F3* __restrict__ d = reinterpret_cast<F3*>(dst + (size_t)img * n * 3);
+  for (uint32_t base = blockIdx.x * 1024u; base < n; base += gridDim.x * 1024u) {
+    F3 in[4] = {};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t p = base + k * 256 + threadIdx.x;
+      if (p < n) in[k] = load_stream(s + p);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __builtin_amdgcn_sched_barrier(0);  // one pixel's terms at a time: 2 T registers
+      const uint32_t p = base + k * 256 + threadIdx.x;
+      float x[3] = {in[k].x, in[k].y, in[k].z};
+      if (P.neg) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = 1.0f - clamp01((clamp01(x[c]) - ip.neg_lo[c]) * ip.neg_inv[c]);
+      }
+      double e[SS_MAX_CCM_TERMS];
+      careful::expand_shared_roots(KIND, T, (double)x[0], (double)x[1], (double)x[2], e);
+      double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        o0 += coef[t][0] * e[t];
+        o1 += coef[t][1] * e[t];
+        o2 += coef[t][2] * e[t];
+      }
+      if (p < n) store_stream(d + p, F3{(float)o0, (float)o1, (float)o2});
+    }
+  }
+}
+
+hipError_t launch_ccm_f64(const ChainParams& P, int batch, const float* src, float* dst, hipStream_t st) {
+  uint64_t blocks = ((uint64_t)P.n_px + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 32768) blocks = 32768;
+  const dim3 grid((unsigned)blocks, (unsigned)batch, 1);
+#define SS_F64_CASE(KIND, T)                                                                          \
+  if (P.ccm_kind == KIND && P.ccm_terms == T) {                                                       \
+    hipLaunchKernelGGL((ccm_f64_kernel<KIND, T>), grid, dim3(256), 0, st, P, src, dst);               \
+    return hipGetLastError();                                                                         \
+  }
+  SS_F64_CASE(SS_CCM_CHEUNG, 5) SS_F64_CASE(SS_CCM_CHEUNG, 7) SS_F64_CASE(SS_CCM_CHEUNG, 8) SS_F64_CASE(SS_CCM_CHEUNG, 10)
+  SS_F64_CASE(SS_CCM_CHEUNG, 11) SS_F64_CASE(SS_CCM_CHEUNG, 14) SS_F64_CASE(SS_CCM_CHEUNG, 16) SS_F64_CASE(SS_CCM_CHEUNG, 17)
+  SS_F64_CASE(SS_CCM_CHEUNG, 19) SS_F64_CASE(SS_CCM_CHEUNG, 20) SS_F64_CASE(SS_CCM_CHEUNG, 22)
+  SS_F64_CASE(SS_CCM_ROOTPOLY, 6) SS_F64_CASE(SS_CCM_ROOTPOLY, 13) SS_F64_CASE(SS_CCM_ROOTPOLY, 22)
+#undef SS_F64_CASE
+  return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -88,7 +88,7 @@ __device__ __forceinline__ void lab_to_rgb(const Lab3 q, double rgb[3]) {
 }
 
 // term lists of colour.characterisation: matrix_augmented_Cheung2004 / polynomial_expansion_Finlayson2015 (roots)
-__device__ inline int expand(int kind, int terms, double R, double G, double B, double e[SS_MAX_CCM_TERMS]) {
+__device__ __forceinline__ int expand(int kind, int terms, double R, double G, double B, double e[SS_MAX_CCM_TERMS]) {
   int n = 0;
   e[n++] = R;
   e[n++] = G;
@@ -171,6 +171,65 @@ __device__ inline int expand(int kind, int terms, double R, double G, double B, 
   e[n++] = sroot4(R * R * G * B);
   e[n++] = sroot4(G * G * R * B);
   e[n++] = sroot4(B * B * R * G);
+  return n;
+}
+
+// The same term lists for the dense float64 colour-correction pass: the root-polynomial terms as products of the
+// three channels' own signed roots (sign(x y) |x y|^p = spow(x, p) spow(y, p): three square, cube and fourth roots
+// instead of three, seven and nine), which in float64 agree with the roots of the products to a few 1e-16.
+__device__ __forceinline__ int expand_shared_roots(int kind, int terms, double R, double G, double B, double e[SS_MAX_CCM_TERMS]) {
+  if (kind != SS_CCM_ROOTPOLY || terms <= 3) return expand(kind, terms, R, G, B, e);
+  int n = 0;
+  e[n++] = R;
+  e[n++] = G;
+  e[n++] = B;
+  if (terms == 6) {
+    const double hr = sroot2(R), hg = sroot2(G), hb = sroot2(B);
+    e[n++] = hr * hg;
+    e[n++] = hg * hb;
+    e[n++] = hr * hb;
+    return n;
+  }
+  // (a second Newton step: coefficients of 10^5 multiply these, and rpow's 1e-12 would show as 1e-7 in the pixel;
+  // the step is of size 1e-12 itself, so the float32 reciprocal of its denominator serves, as in rpow)
+  auto cube_root = [](double x) -> double {
+    const double y = rpow<1, 3>(x);
+    if (y == 0.0) return 0.0;
+    return y - (y * y * y - x) * (double)__builtin_amdgcn_rcpf(3.0f * (float)(y * y));
+  };
+  const double cr = cube_root(R), cg = cube_root(G), cb = cube_root(B);
+  const double cr2 = cr * cr, cg2 = cg * cg, cb2 = cb * cb;
+  if (terms == 13) {
+    const double hr = sroot2(R), hg = sroot2(G), hb = sroot2(B);
+    e[n++] = hr * hg;
+    e[n++] = hg * hb;
+    e[n++] = hr * hb;
+  } else {
+    const double qr = sroot4(R), qg = sroot4(G), qb = sroot4(B);             // signed fourth roots
+    const double hr = qr * fabs(qr), hg = qg * fabs(qg), hb = qb * fabs(qb);  // signed square roots
+    e[n++] = hr * hg;
+    e[n++] = hg * hb;
+    e[n++] = hr * hb;
+  }
+  e[n++] = cr * cg2;
+  e[n++] = cg * cb2;
+  e[n++] = cr * cb2;
+  e[n++] = cg * cr2;
+  e[n++] = cb * cg2;
+  e[n++] = cb * cr2;
+  e[n++] = (cr * cg) * cb;
+  if (terms == 13) return n;
+  const double qr = sroot4(R), qg = sroot4(G), qb = sroot4(B);
+  const double ar = qr * qr, ag = qg * qg, ab = qb * qb;  // |x|^(1/2)
+  e[n++] = (ar * qr) * qg;  // (R^3 G)^(1/4)
+  e[n++] = (ar * qr) * qb;
+  e[n++] = (ag * qg) * qr;
+  e[n++] = (ag * qg) * qb;
+  e[n++] = (ab * qb) * qr;
+  e[n++] = (ab * qb) * qg;
+  e[n++] = ar * (qg * qb);  // (R^2 G B)^(1/4)
+  e[n++] = ag * (qr * qb);
+  e[n++] = ab * (qr * qg);
   return n;
 }
 

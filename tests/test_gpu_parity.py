@@ -79,10 +79,8 @@ def test_cheung_polynomial_terms(swatches, terms):
     ccm = fit(M_T, M_R, method="Cheung 2004", terms=terms)
     got = run_chain_dev(img, ccm=ccm, out="f32")[0]
     want = lv.colour_correction(img, M_T, M_R, "Cheung 2004", terms=terms)
-    # float32 evaluation error scales with sum |coef * term|
-    mag = np.abs(lv.expand(img.reshape(-1, 3).astype(np.float64), "Cheung 2004", terms=terms)) @ np.abs(ccm[0]).T
-    tol = max(F32_TOL, 4e-7 * float(mag.max()))
-    assert np.max(np.abs(got - want)) <= tol
+    # (where float32 cannot hold the sum of |coefficient * term| to the bar, the library evaluates the pixel in float64)
+    assert np.max(np.abs(got - want)) <= F32_TOL
 
 
 @pytest.mark.parametrize("degree", [1, 2, 3, 4])
@@ -93,9 +91,9 @@ def test_root_polynomial_degrees(swatches, degree):
     ccm = fit(M_T, M_R, method="Finlayson 2015", degree=degree)
     got = run_chain_dev(img, ccm=ccm, out="f32")[0]
     want = lv.colour_correction(img, M_T, M_R, "Finlayson 2015", degree=degree, root_polynomial_expansion=True)
-    mag = np.abs(lv.expand(img.reshape(-1, 3).astype(np.float64), "Finlayson 2015", degree=degree)) @ np.abs(ccm[0]).T
-    tol = max(F32_TOL, 4e-7 * float(mag.max()))
-    assert np.max(np.abs(got - want)) <= tol
+    # (the degree-4 fit on 24 swatches extrapolates to values in the thousands where a channel is almost zero: a float32
+    # output holds those to half a unit of its last place, 1.2e-4 at 2,000, and no closer)
+    assert np.all(np.abs(got - want) <= np.maximum(F32_TOL, 0.5 * np.spacing(np.abs(want).astype(np.float32)).astype(np.float64) * 1.001))
     np.testing.assert_array_equal(got[0, 0], 0.0)
 
 
@@ -612,11 +610,6 @@ def fuzz_case(seed, M_T, M_R):
         gains = [1.0]  # the reference clips to [0,1] before these stages
     final_clip = bool(rng.random() < 0.7) or sh is not None or usm is not None
     out = ["f32", "f32_srgb", "u16", "u8"][int(rng.integers(0, 4))]
-    high_order = ccm_kw is not None and (ccm_kw.get("terms", 3) > 8 or ccm_kw.get("degree", 1) >= 3)
-    if high_order and out != "f32":
-        # their float32 error is a multiple of the 1e-5 bar (sum of |coefficient * term|, see the term tests), and
-        # the sRGB encode multiplies it by up to 12.92 in a dark channel
-        out = "f32"
     if out != "f32" and not final_clip and ccm_kw is not None:
         final_clip = True  # encoded outputs of unclipped data are not a reference path
     kw = dict(gains=gains, final_clip=final_clip, out=out)
@@ -673,8 +666,7 @@ def test_random_stage_combinations(swatches, seed):
             extra = _blur_allowance(want / scale, usm[0], True) * scale if usm is not None else 0.0
             assert np.all(diff <= 1 + np.floor(F32_TOL * scale + extra)), (seed, list(kw.keys()), int(diff.max()))
         else:
-            # polynomial corrections of high order lose absolute accuracy with the size of their terms
-            tol = F32_TOL * (1 if ccm_kw is None or ccm_kw.get("terms", 3) <= 3 and ccm_kw.get("degree", 1) <= 1 else 4)
+            tol = F32_TOL
             err = np.abs(got[i] - want)
             extra = _blur_allowance(want, usm[0], out == "f32_srgb") if usm is not None else 0.0
             assert np.all(err <= tol + extra), (seed, out, ccm_kw, sh, usm, len(gains), float(err.max()))
