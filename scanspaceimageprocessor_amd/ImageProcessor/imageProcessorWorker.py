@@ -135,6 +135,10 @@ class ImageCorrectionWorker:
         # overwrites with the next image (no allocation, no staging copy: 11 -> 7 ms per 24 MP image).  For
         # headless runs whose writer and preview consumer are done with an image before the next one starts.
         self.reuse_output_buffers = False
+        # Images in flight in `run`: 2 = while image i is on the GPU, a helper thread decodes and uploads image i + 1 and
+        # another writes image i - 1 (two contexts, i.e. two streams: the upload of one image and the download of another
+        # share the link, one direction each).  1 = the reference's strictly sequential loop.
+        self.pipeline_depth = 2
         self._ccm = None
 
     def cancel(self):
@@ -329,40 +333,41 @@ class ImageCorrectionWorker:
         kw["final_clip"] = True
         return kw
 
-    def process_array(self, raw_img_float: np.ndarray, img_path: str = ""):
-        """Steps 5-7 of the reference's ``run`` on one decoded image, resident on the GPU:
-        returns ``(encoded, preview_uint8)``.  ``raw_img_float`` is the output of the RAW decode
-        BEFORE negative inversion (the inversion runs on the device here).  A uint16 array is taken as the
-        RAW decoder's 16-bit output: it is uploaded as it is and divided by 65535 on the device (the
-        reference's ``np.array(rgb, dtype=np.float32) / 65535.0``, imageProcessorWorker.py:313)."""
-        ctx = default_context()
-        raw16 = isinstance(raw_img_float, np.ndarray) and raw_img_float.dtype == np.uint16
-        img = np.ascontiguousarray(raw_img_float, dtype=np.uint16 if raw16 else np.float32)
+    def _upload_image(self, ctx, raw_img):
+        """Upload step of ``process_array``: the decoded image into the context's "worker.src" buffer (a uint16 image
+        goes through the output buffer and is divided by 65535 on the device).  Returns ``(h, w)``."""
+        raw16 = isinstance(raw_img, np.ndarray) and raw_img.dtype == np.uint16
+        img = np.ascontiguousarray(raw_img, dtype=np.uint16 if raw16 else np.float32)
         if img.ndim != 3 or img.shape[2] != 3:
             raise ValueError(f"expected an (H, W, 3) image, got shape {img.shape}")
         h, w, _ = img.shape
-        kind = self._out_kind(self.output_format)
-        kw = self.chain_stages(img_path)
-        # buffers stay with the thread's context from image to image
+        # buffers stay with the context from image to image
         f32_bytes = h * w * 3 * 4
         src = ctx.workspace("worker.src", f32_bytes)
         dst = ctx.workspace("worker.dst", f32_bytes)
-        neg = ctx.workspace("worker.neg", _lib.SS_NEG_PARAM_STRIDE * 4) if self.negative_mode else None
         if raw16:
             ctx.upload(dst, img)                       # staged in the output buffer, which is free until the chain runs
             ctx.unpack_u16(dst, src, h * w * 3)
         else:
             ctx.upload(src, img)
+        return h, w
+
+    def _device_chain(self, ctx, h, w, img_path):
+        """Steps 5-7 on the image in "worker.src": queues the kernels on the context's stream and returns
+        ``(kind, encoded_dev, preview_dev)`` - the device buffers that will hold the encoded image and the 8-bit
+        preview (``None``: the encoded image is its own preview).  Nothing here waits for the GPU except the masked
+        export's pixel count."""
+        kind = self._out_kind(self.output_format)
+        kw = self.chain_stages(img_path)
+        f32_bytes = h * w * 3 * 4
+        src = ctx.workspace("worker.src", f32_bytes)
+        dst = ctx.workspace("worker.dst", f32_bytes)
         if self.negative_mode:
+            neg = ctx.workspace("worker.neg", _lib.SS_NEG_PARAM_STRIDE * 4)
             ctx.negative_params(src, h, w, 1, self.negative_low_pct, self.negative_high_pct,
                                 editingTools.NUMPY_LEGACY_PERCENTILE, neg)
             kw.update(neg=True, neg_params_dev=neg)
-        def host_array(tag, dtype):
-            if self.reuse_output_buffers:
-                return ctx.host_workspace(tag, (h, w, 3), dtype)
-            return np.empty((h, w, 3), dtype=dtype)
-
-        encoded = host_array("worker.encoded", _lib.OUT_DTYPES[kind])
+        eight_bit = np.dtype(_lib.OUT_DTYPES[kind]) == np.uint8
         if getattr(self, "export_masked", False):
             # reference order (imageProcessorWorker.py:902-912): chain -> _apply_masking -> encode.  The chain
             # leaves the clipped linear image in `dst`, the masking zeroes regions in place, and the encode
@@ -371,26 +376,41 @@ class ImageCorrectionWorker:
             self._apply_masking_device(ctx, dst, h, w)
             # The preview is made from the array that is encoded (imageProcessorWorker.py:907-922): both outputs
             # of one pass over it.
-            if np.dtype(_lib.OUT_DTYPES[kind]) == np.uint8:
+            if eight_bit:
                 ctx.chain_run(make_desc(h, w, 1, out=kind), dst, src)
-                ctx.download(encoded, src)
-                return encoded, encoded
+                return kind, src, None
             pre = ctx.workspace("worker.preview", h * w * 3)
             ctx.chain_run2(make_desc(h, w, 1, out=kind), dst, src, _lib.SS_OUT_U8_LINEAR, pre)
-            ctx.download(encoded, src)
-            preview = host_array("worker.preview", np.uint8)
-            ctx.download(preview, pre)
-            return encoded, preview
-        if np.dtype(_lib.OUT_DTYPES[kind]) == np.uint8:
+            return kind, src, pre
+        if eight_bit:
             ctx.chain_run(make_desc(h, w, 1, out=kind, **kw), src, dst)
-            ctx.download(encoded, dst)
-            return encoded, encoded
+            return kind, dst, None
         # one pass over the image, two outputs: the encoded image and the 8-bit linear preview of the same pixels
         pre = ctx.workspace("worker.preview", h * w * 3)
         ctx.chain_run2(make_desc(h, w, 1, out=kind, **kw), src, dst, _lib.SS_OUT_U8_LINEAR, pre)
-        ctx.download(encoded, dst)
+        return kind, dst, pre
+
+    def process_array(self, raw_img_float: np.ndarray, img_path: str = ""):
+        """Steps 5-7 of the reference's ``run`` on one decoded image, resident on the GPU:
+        returns ``(encoded, preview_uint8)``.  ``raw_img_float`` is the output of the RAW decode
+        BEFORE negative inversion (the inversion runs on the device here).  A uint16 array is taken as the
+        RAW decoder's 16-bit output: it is uploaded as it is and divided by 65535 on the device (the
+        reference's ``np.array(rgb, dtype=np.float32) / 65535.0``, imageProcessorWorker.py:313)."""
+        ctx = default_context()
+        h, w = self._upload_image(ctx, raw_img_float)
+        kind, enc_dev, pre_dev = self._device_chain(ctx, h, w, img_path)
+
+        def host_array(tag, dtype):
+            if self.reuse_output_buffers:
+                return ctx.host_workspace(tag, (h, w, 3), dtype)
+            return np.empty((h, w, 3), dtype=dtype)
+
+        encoded = host_array("worker.encoded", _lib.OUT_DTYPES[kind])
+        ctx.download(encoded, enc_dev)
+        if pre_dev is None:
+            return encoded, encoded
         preview = host_array("worker.preview", np.uint8)
-        ctx.download(preview, pre)
+        ctx.download(preview, pre_dev)
         return encoded, preview
 
     # ------------------------------------------------------------------ masking
@@ -441,16 +461,12 @@ class ImageCorrectionWorker:
     def _decode_raw(self, img_path: str) -> np.ndarray:
         """The RAW decode of ``load_image`` (imageProcessorWorker.py:304-313).  Returns the decoder's uint16 image
         (``process_array`` divides by 65535 on the device); a ``raw_loader`` hook may return uint16 or float data."""
-        if self.raw_loader is not None:
-            arr = np.asarray(self.raw_loader(img_path))
-            return arr if arr.dtype == np.uint16 else np.asarray(arr, dtype=np.float32)
-        self.signals.log.emit(f"[RAW] Using original path for rawpy: {img_path}")
-        import rawpy  # host decode stays on LibRaw
-
-        with rawpy.imread(img_path) as raw:
-            rgb = raw.postprocess(output_bps=16, gamma=(1, 1), no_auto_bright=True, use_camera_wb=True,
-                                  output_color=rawpy.ColorSpace.sRGB)
-            return np.ascontiguousarray(rgb, dtype=np.uint16)
+        logs = []
+        try:
+            return self._decode_raw_quiet(img_path, logs)
+        finally:
+            for msg in logs:
+                self.signals.log.emit(msg)
 
     def _write(self, out_path: str, encoded: np.ndarray, ext: str) -> None:
         if self.image_writer is not None:
@@ -514,7 +530,18 @@ class ImageCorrectionWorker:
     # ------------------------------------------------------------------ main loop
 
     def run(self):
-        """Reference imageProcessorWorker.py:815-977 without metadata embedding."""
+        """Reference imageProcessorWorker.py:815-977 without metadata embedding.  With ``pipeline_depth`` 2 (the default)
+        and more than one image the loop is two images deep (``_run_pipelined``); the results are those of the
+        sequential loop bit for bit, and so is each image's own sequence of signals - only the signals of neighbouring
+        images interleave ('started' of image i + 1 comes before 'finished' of image i)."""
+        if self.pipeline_depth >= 2 and len(self.images) > 1:
+            return self._run_pipelined()
+        return self._run_sequential()
+
+    def _default_out_path(self, img_path):
+        return os.path.join(self.output_folder, os.path.splitext(os.path.basename(img_path))[0] + self.output_format)
+
+    def _run_sequential(self):
         ext = self.output_format
         for img_path in self.images:
             t0 = time.time()
@@ -545,6 +572,164 @@ class ImageCorrectionWorker:
             except Exception as e:
                 self.signals.log.emit(f"[Processing Error] {img_path}: {e}")
                 if out_path is None:
-                    out_path = os.path.join(self.output_folder,
-                                            os.path.splitext(os.path.basename(img_path))[0] + self.output_format)
+                    out_path = self._default_out_path(img_path)
                 self.signals.status.emit(img_path, 'error', time.time() - t0, out_path)
+
+    def _run_pipelined(self):
+        """The loop of ``run`` two images deep.  Image i lives in slot i % 2: a context of its own (its stream, its
+        device buffers) and two page-locked output arrays.
+
+            helper thread   decode image i + 1, upload it (and divide by 65535) on its slot's context
+            this thread     queue the kernels and the downloads of image i; then finish image i - 1: wait for its
+                            stream, hand it to the writer thread; signals
+            writer thread   write image i - 1
+
+        The error contract is the reference's (imageProcessorWorker.py:950-970): whatever goes wrong with one image is
+        logged, reported as status 'error', and the loop goes on with the next.  All signals are emitted by this
+        thread."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        ext = self.output_format
+        # One context per slot (its stream, device buffers and page-locked arrays), kept by the worker from run to run.
+        # They are made when the first image has been decoded: a batch whose files cannot be read is reported image by
+        # image without a GPU ever being asked for.
+        slots = [dict(k=0), dict(k=1)]
+
+        def slot_ctx(slot):
+            from .. import Context
+
+            ctxs = self.__dict__.setdefault("_pipeline_ctxs", {})
+            ctx = ctxs.get(slot["k"])
+            if ctx is None or ctx.handle is None:
+                ctx = ctxs[slot["k"]] = Context(_lib.default_device())
+            slot["ctx"] = ctx
+            return ctx
+
+        loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="scanspace-load")
+        writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="scanspace-write")
+
+        def load(img_path, slot):  # (helper thread) -> (h, w, log lines); raises what the decode or the upload raises
+            logs = []  # the decoder's log lines: emitted by the loop's thread, not from here
+            raw = self._decode_raw_quiet(img_path, logs)
+            ctx = slot_ctx(slot)
+            h, w = self._upload_image(ctx, raw)
+            ctx.sync()  # (the slot's context goes back to the loop's thread idle)
+            return h, w, logs
+
+        def start(i):  # image i enters the pipeline: 'started', then its decode on the helper thread
+            img_path = self.images[i]
+            job = dict(path=img_path, t0=time.time(), out_path=None, slot=slots[i % 2], state="loading")
+            try:
+                job["out_path"] = self.construct_export_path(img_path)
+                if self.from_network:
+                    self.signals.status.emit('started')
+                else:
+                    self.signals.status.emit(img_path, 'started', 0.0, job["out_path"])
+                self.signals.log.emit(f"[Worker] Starting {os.path.basename(img_path)} -> {os.path.basename(job['out_path'])}")
+                job["load"] = loader.submit(load, img_path, job["slot"])
+            except Exception as e:
+                fail(job, e)
+            return job
+
+        def fail(job, e, kind="Processing Error"):
+            self.signals.log.emit(f"[{kind}] {job['path']}: {e}")
+            out_path = job["out_path"] if job["out_path"] is not None else self._default_out_path(job["path"])
+            self.signals.status.emit(job["path"], 'error', time.time() - job["t0"], out_path)
+            job["state"] = "done"
+
+        def launch(job):  # decoded and uploaded -> kernels and downloads queued on the slot's stream
+            h, w, logs = job["load"].result()
+            job["state"] = "loaded"
+            ctx = job["slot"]["ctx"]
+            for msg in logs:
+                self.signals.log.emit(msg)
+            kind, enc_dev, pre_dev = self._device_chain(ctx, h, w, job["path"])
+            job["encoded"] = ctx.host_workspace("worker.encoded", (h, w, 3), _lib.OUT_DTYPES[kind])
+            ctx.download_async(job["encoded"], enc_dev)
+            job["preview"] = job["encoded"]
+            if pre_dev is not None:
+                job["preview"] = ctx.host_workspace("worker.preview", (h, w, 3), np.uint8)
+                ctx.download_async(job["preview"], pre_dev)
+            job["state"] = "on the GPU"
+
+        def write(job):  # (writer thread)
+            self._write(job["out_path"], job["encoded"], ext)
+            # The slot's page-locked arrays are overwritten two images later: a listener that keeps the preview gets
+            # an array of its own, unless the caller has agreed to reused buffers.
+            return job["preview"] if self.reuse_output_buffers else job["preview"].copy()
+
+        def collect(job):  # wait for the slot's stream, hand the image to the writer thread
+            job["slot"]["ctx"].sync()
+            job["write"] = writer.submit(write, job)
+            job["state"] = "writing"
+
+        def finish(job):  # written: the image's last signals; its slot's output arrays are free again
+            preview = job["write"].result()
+            self.signals.log.emit(f"[Saved] {job['out_path']}")
+            self.signals.preview.emit([preview, job["out_path"]])
+            self.signals.status.emit(job["path"], 'finished', time.time() - job["t0"], job["out_path"])
+            job["state"] = "done"
+
+        def advance(job, step):
+            if job is None or job["state"] == "done":
+                return
+            try:
+                step(job)
+            except Exception as e:
+                fail(job, e, "Image Load Error" if job["state"] == "loading" else "Processing Error")
+
+        try:
+            n = len(self.images)
+            jobs = [None] * n
+            jobs[0] = start(0)
+            for i in range(n):
+                cur, prev = jobs[i], jobs[i - 1] if i > 0 else None
+                if cur["state"] == "loading":
+                    try:
+                        cur["load"].result()
+                    except Exception:
+                        pass  # (reported by `launch` below)
+                if self.cancelled:
+                    for job in (prev, ):
+                        if job is not None and job["state"] == "on the GPU":
+                            advance(job, collect)
+                        if job is not None and job["state"] == "writing":
+                            advance(job, finish)
+                    self.signals.log.emit("[Worker] Cancelled by user. Exiting thread.")
+                    if cur["state"] != "done":
+                        self.signals.status.emit(cur["path"], 'cancelled', time.time() - cur["t0"], cur["out_path"])
+                    return
+                # the slot's output arrays were last used by image i - 2: its write must be over before new downloads
+                if i >= 2 and jobs[i - 2]["state"] == "writing":
+                    advance(jobs[i - 2], finish)
+                if cur["state"] == "loading":
+                    advance(cur, launch)
+                    if cur["state"] == "loaded":  # (launch stopped half-way without raising: cannot happen)
+                        cur["state"] = "done"
+                if prev is not None and prev["state"] == "on the GPU":
+                    advance(prev, collect)  # (waits for image i - 1 only: image i runs on the other stream)
+                if i + 1 < n:
+                    jobs[i + 1] = start(i + 1)  # its slot is the one image i - 1 has just left
+                if prev is not None and prev["state"] == "writing":
+                    advance(prev, finish)
+            last = jobs[n - 1]
+            if last["state"] == "on the GPU":
+                advance(last, collect)
+            if last["state"] == "writing":
+                advance(last, finish)
+        finally:
+            loader.shutdown(wait=True)
+            writer.shutdown(wait=True)
+
+    def _decode_raw_quiet(self, img_path, logs):
+        """``_decode_raw`` for the helper thread: its log lines go to ``logs`` (the loop's thread emits them)."""
+        if self.raw_loader is not None:
+            arr = np.asarray(self.raw_loader(img_path))
+            return arr if arr.dtype == np.uint16 else np.asarray(arr, dtype=np.float32)
+        logs.append(f"[RAW] Using original path for rawpy: {img_path}")
+        import rawpy  # host decode stays on LibRaw
+
+        with rawpy.imread(img_path) as raw:
+            rgb = raw.postprocess(output_bps=16, gamma=(1, 1), no_auto_bright=True, use_camera_wb=True,
+                                  output_color=rawpy.ColorSpace.sRGB)
+            return np.ascontiguousarray(rgb, dtype=np.uint16)

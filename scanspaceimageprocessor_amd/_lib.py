@@ -463,10 +463,15 @@ class Context:
 _tls = threading.local()
 
 
+def default_device():
+    """The GPU a process uses when it names none: SCANSPACE_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
+    return int(os.environ.get("SCANSPACE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
 def default_context(device=None):
     """Per-thread context (the reference runs several worker threads at once)."""
     if device is None:
-        device = int(os.environ.get("SCANSPACE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        device = default_device()
     ctxs = getattr(_tls, "ctxs", None)
     if ctxs is None:
         ctxs = _tls.ctxs = {}

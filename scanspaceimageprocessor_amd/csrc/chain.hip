@@ -388,26 +388,41 @@ __global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, int l
     }
     return ((unsigned long long)img << 32) | px;
   };
-  auto evaluate = [&](unsigned long long entry) {
-    const uint32_t img = (uint32_t)(entry >> 32), px = (uint32_t)entry;
-    const size_t at = (size_t)img * (size_t)P.n_px + px;
-    const float* sp = src + at * 3;
-    float Lb = 0.0f;
+  // A recorded pixel's inputs (its source pixel and, behind an unsharp mask, the blurred lightness the tile kernel left
+  // in its output slot) are fetched one pixel ahead of the arithmetic: the scattered loads of the next pixel are in
+  // flight during the ~thousand float64 instructions of this one, where fetching and evaluating in turn left the
+  // kernel waiting for memory two thirds of the time.
+  struct Fetched {
+    size_t at;
+    uint32_t img;
+    float sr, sg, sb, Lb;
+  };
+  auto fetch = [&](unsigned long long entry) -> Fetched {
+    Fetched f;
+    f.img = (uint32_t)(entry >> 32);
+    const uint32_t px = (uint32_t)entry;
+    f.at = (size_t)f.img * (size_t)P.n_px + px;
+    const float* sp = src + f.at * 3;
+    f.sr = sp[0], f.sg = sp[1], f.sb = sp[2];
+    f.Lb = 0.0f;
     if (P.usm) {  // left by the tile kernel in the pixel's output slot
       if (out_kind == SS_OUT_U16_SRGB) {
-        const uint16_t* d = reinterpret_cast<const uint16_t*>(dst) + at * 3;
-        Lb = __uint_as_float((uint32_t)d[0] | ((uint32_t)d[1] << 16));
+        const uint16_t* d = reinterpret_cast<const uint16_t*>(dst) + f.at * 3;
+        f.Lb = __uint_as_float((uint32_t)d[0] | ((uint32_t)d[1] << 16));
       } else {
-        Lb = reinterpret_cast<const float*>(dst)[at * 3];
+        f.Lb = reinterpret_cast<const float*>(dst)[f.at * 3];
       }
     }
+    return f;
+  };
+  auto evaluate = [&](const Fetched& f) {
     double v3[3];
-    careful_pixel(Pk, (int)img, sp[0], sp[1], sp[2], Lb, enc, v3);
+    careful_pixel(Pk, (int)f.img, f.sr, f.sg, f.sb, f.Lb, enc, v3);
     if (out_kind == SS_OUT_U16_SRGB) {
-      uint16_t* d = reinterpret_cast<uint16_t*>(dst) + at * 3;
+      uint16_t* d = reinterpret_cast<uint16_t*>(dst) + f.at * 3;
       for (int c = 0; c < 3; ++c) d[c] = (uint16_t)fmin(fmax(v3[c] * 65535.0, 0.0), 65535.0);
     } else {
-      float* d = reinterpret_cast<float*>(dst) + at * 3;
+      float* d = reinterpret_cast<float*>(dst) + f.at * 3;
       d[0] = (float)v3[0], d[1] = (float)v3[1], d[2] = (float)v3[2];
     }
   };
@@ -436,8 +451,23 @@ __global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, int l
     if (threadIdx.x == 0) atomicAdd(P.risk_count, total);
     // the list: the carried pixels, then this chunk's; whole groups of 256 are evaluated now
     const uint32_t listed = carried + total, whole = listed & ~255u;
-    for (uint32_t v = threadIdx.x; v < whole; v += 256)
-      evaluate(v < carried ? carry[v] : locate(chunk, v - carried));
+    {
+      auto entry_of = [&](uint32_t v) -> unsigned long long { return v < carried ? carry[v] : locate(chunk, v - carried); };
+      uint32_t v = threadIdx.x;
+      bool have = v < whole;
+      Fetched cur{};
+      if (have) cur = fetch(entry_of(v));
+      while (have) {
+        const uint32_t vn = v + 256;
+        const bool have_next = vn < whole;
+        Fetched next{};
+        if (have_next) next = fetch(entry_of(vn));
+        evaluate(cur);
+        cur = next;
+        have = have_next;
+        v = vn;
+      }
+    }
     const uint32_t rest = whole + threadIdx.x;  // what is left becomes the carry
     unsigned long long keep = 0ull;
     if (rest < listed) keep = rest < carried ? carry[rest] : locate(chunk, rest - carried);
@@ -446,7 +476,7 @@ __global__ __launch_bounds__(256) void careful_kernel(const ChainParams P, int l
     carried = listed - whole;
   }
   __syncthreads();
-  if (threadIdx.x < carried) evaluate(carry[threadIdx.x]);
+  if (threadIdx.x < carried) evaluate(fetch(carry[threadIdx.x]));
 }
 
 hipError_t launch_careful(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st) {

@@ -71,7 +71,8 @@ def test_run_in_no_chart_negative_mode_writes_and_signals(tmp_path):
     w.raw_loader = lambda path: neg if path == "n1.nef" else neg[::-1].copy()
     w.image_writer = lambda out_path, arr, ext: written.__setitem__(out_path, arr.copy())
     w.run()
-    assert states == ["started", "finished", "started", "finished"]
+    # two images deep: image 2 is being decoded while image 1 is on the GPU
+    assert states == ["started", "started", "finished", "finished"]
     assert len(written) == 2 and len(previews) == 2
     for path, src in (("n1", neg), ("n2", neg[::-1])):
         got = written[str(tmp_path / (path + ".tiff"))]
@@ -309,3 +310,73 @@ def test_asynchronous_copies_of_page_locked_buffers_run_in_stream_order():
     finally:
         ctx.free(src)
         ctx.free(dst)
+
+
+def _run_worker(depth, images, loader, **kw):
+    M_T, M_R = inputs.synthetic_swatches()
+    ipw.set_reference_swatches(M_R)
+    written, previews, events, logs = {}, {}, [], []
+    sig = ipw.WorkerSignals()
+    sig.preview.connect(lambda d: previews.__setitem__(d[1], d[0].copy()))
+    sig.status.connect(lambda *a: events.append((a[0], a[1])))
+    sig.log.connect(logs.append)
+    w = ipw.ImageCorrectionWorker(images, M_T, "/tmp/out", sig, output_format=".tiff", tiff_bitdepth=16, **kw)
+    w.pipeline_depth = depth
+    w.raw_loader = loader
+    w.image_writer = lambda out_path, arr, ext: written.__setitem__(out_path, arr.copy())
+    w.image_metadata_map = {p: {"average_exposure": str(1.0 + 0.05 * i)} for i, p in enumerate(images)}
+    w.run()
+    return written, previews, events, logs
+
+
+def test_pipelined_run_is_the_sequential_run_bit_for_bit():
+    """Five images of two sizes (uint16 from the 'decoder' and float32), two deep against one after the other: the
+    same files and previews, every image's own signals in order, 'finished' in image order."""
+    rng = np.random.default_rng(21)
+    data = {}
+    for i in range(5):
+        h, w = (120, 176) if i % 2 == 0 else (97, 150)
+        img = inputs.linear_image(30 + i, h, w)
+        data[f"img{i}.nef"] = (img * 65535.0).astype(np.uint16) if i != 3 else img
+    images = list(data)
+    loader = lambda path: data[path]
+    seq = _run_worker(1, images, loader, shadow_adj=10.0, exposure_adj=0.1)
+    pipe = _run_worker(2, images, loader, shadow_adj=10.0, exposure_adj=0.1)
+    assert list(seq[0]) == list(pipe[0]) == [f"/tmp/out/img{i}.tiff" for i in range(5)]
+    for path in seq[0]:
+        np.testing.assert_array_equal(seq[0][path], pipe[0][path])
+        np.testing.assert_array_equal(seq[1][path], pipe[1][path])
+    assert [e for e in seq[2]] == [(p, s) for p in images for s in ("started", "finished")]
+    for p in images:  # each image: started, then finished
+        own = [s for q, s in pipe[2] if q == p]
+        assert own == ["started", "finished"]
+    assert [q for q, s in pipe[2] if s == "finished"] == images
+    # the loop really was two deep: the second image started before the first finished
+    assert pipe[2].index((images[1], "started")) < pipe[2].index((images[0], "finished"))
+
+
+def test_pipelined_run_survives_a_bad_image_in_the_middle():
+    """imageProcessorWorker.py:950-970: an image that cannot be loaded, and one that cannot be processed, are
+    reported as 'error' and the rest of the batch finishes."""
+    good = (inputs.linear_image(40, 80, 120) * 65535.0).astype(np.uint16)
+
+    def loader(path):
+        if path == "broken.nef":
+            raise IOError("truncated file")
+        if path == "flat.nef":
+            return np.zeros((80, 120), np.uint16)  # not (H, W, 3): the upload refuses it
+        return good
+
+    images = ["a.nef", "broken.nef", "b.nef", "flat.nef", "c.nef"]
+    written, previews, events, logs = _run_worker(2, images, loader)
+    assert sorted(written) == ["/tmp/out/a.tiff", "/tmp/out/b.tiff", "/tmp/out/c.tiff"]
+    final = {p: [s for q, s in events if q == p][-1] for p in images}
+    assert final == {"a.nef": "finished", "broken.nef": "error", "b.nef": "finished", "flat.nef": "error",
+                     "c.nef": "finished"}
+    assert any("[Image Load Error] broken.nef: truncated file" in m for m in logs)
+    # the same batch one after the other: the same outcome, the same files
+    written1, _, events1, _ = _run_worker(1, images, loader)
+    assert {p: [s for q, s in events1 if q == p][-1] for p in images} == final
+    assert sorted(written1) == sorted(written)
+    for path in written:
+        np.testing.assert_array_equal(written[path], written1[path])
