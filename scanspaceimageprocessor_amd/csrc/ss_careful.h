@@ -36,6 +36,19 @@ __device__ __forceinline__ double spow(double a, double p) {
 // (y^M stays inside 2^+-60), and the result by 2^(-N k).
 // Divisions by constants are written as multiplications by the constant's reciprocal throughout this file for the
 // same reason: a rounding of 1e-16 either way, where results are needed to 1e-9.
+// v^K by squaring (12 -> 4 multiplications, 5 -> 3)
+template <int K>
+__device__ __forceinline__ double ipow(double v) {
+  if constexpr (K == 1) {
+    return v;
+  } else if constexpr (K % 2 == 0) {
+    const double h = ipow<K / 2>(v);
+    return h * h;
+  } else {
+    return v * ipow<K - 1>(v);
+  }
+}
+
 template <int N, int M>
 __device__ __forceinline__ double rpow(double a) {
   if (a == 0.0) return 0.0;
@@ -43,11 +56,7 @@ __device__ __forceinline__ double rpow(double a) {
   const int k = -(ilogb(x0) / M);
   const double x = ldexp(x0, M * k);
   double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * ((float)N / (float)M));
-  double ym = y, xn = x;
-#pragma unroll
-  for (int j = 1; j < M; ++j) ym *= y;
-#pragma unroll
-  for (int j = 1; j < N; ++j) xn *= x;
+  const double ym = ipow<M>(y), xn = ipow<N>(x);
   y -= y * (ym - xn) * (double)__builtin_amdgcn_rcpf((float)M * (float)ym);
   y = ldexp(y, -N * k);
   return a < 0.0 ? -y : y;
@@ -76,6 +85,26 @@ __device__ __forceinline__ Lab3 rgb_to_lab(const double rgb[3]) {
   double f[3];
   for (int k = 0; k < 3; ++k) f[k] = lab_f((m[3 * k] * r + m[3 * k + 1] * g + m[3 * k + 2] * b) * inv_white[k]);
   return Lab3{116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])};
+}
+
+// The same from pixels that are decoded already (`lin`: what decode() gives for the stage's input)
+__device__ __forceinline__ Lab3 linear_to_lab(const double lin[3]) {
+  const double m[9] = {0.4124, 0.3576, 0.1805, 0.2126, 0.7152, 0.0722, 0.0193, 0.1192, 0.9505};
+  const double inv_white[3] = {0.3290 / 0.3127, 1.0, 0.3290 / (1.0 - 0.3127 - 0.3290)};
+  double f[3];
+  for (int k = 0; k < 3; ++k)
+    f[k] = lab_f((m[3 * k] * lin[0] + m[3 * k + 1] * lin[1] + m[3 * k + 2] * lin[2]) * inv_white[k]);
+  return Lab3{116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])};
+}
+
+// Lab -> XYZ -> linear RGB clipped to [0, 1]: decode() of what lab_to_rgb returns, without the encode / decode pair
+// (decode(clip(encode(x), 0, 1)) = clip(x, 0, 1): encode is increasing and fixes 0 and 1)
+__device__ __forceinline__ void lab_to_linear(const Lab3 q, double lin[3]) {
+  const double inv[9] = {3.2406, -1.5372, -0.4986, -0.9689, 1.8758, 0.0415, 0.0557, -0.2040, 1.0570};
+  const double white[3] = {0.3127 / 0.3290, 1.0, (1.0 - 0.3127 - 0.3290) / 0.3290};
+  const double fy = (q.L + 16.0) * (1.0 / 116.0), fx = q.a * (1.0 / 500.0) + fy, fz = fy - q.b * (1.0 / 200.0);
+  const double x = lab_finv(fx) * white[0], y = lab_finv(fy) * white[1], z = lab_finv(fz) * white[2];
+  for (int k = 0; k < 3; ++k) lin[k] = clip01(inv[3 * k] * x + inv[3 * k + 1] * y + inv[3 * k + 2] * z);
 }
 
 // colour.Lab_to_XYZ, colour.XYZ_to_sRGB (the IEC matrix as published, sRGB encode), clip
@@ -282,10 +311,14 @@ __device__ inline void careful_pixel(const ChainParams* P, int img, float sr, fl
       q.a *= cs;
       q.b *= cs;
     }
-    lab_to_rgb(q, p);
+    // (in front of the sharpen stage, which decodes its input again, the pixel stays decoded: six powers fewer)
+    if (P->usm)
+      lab_to_linear(q, p);
+    else
+      lab_to_rgb(q, p);
   }
   if (P->usm) {  // stage 5 (editingTools.py:745-817)
-    Lab3 q = rgb_to_lab(p);
+    Lab3 q = P->sh ? linear_to_lab(p) : rgb_to_lab(p);
     const double Ln = q.L * 0.01;
     const double amount = (double)P->usm_amount;
     const double thr = (double)P->usm_threshold * 0.01;

@@ -78,9 +78,11 @@ def main():
         d = make_desc(H, W, B, ccm=ccm, gains=[1.0], sh=(0.5, -0.5, 7.0), final_clip=True, out="f32")
     else:
         raise SystemExit("unknown config")
+    torch.cuda.synchronize()  # (the builds' streams do not wait for torch's: the input must be complete first)
     for _ in range(3):
         for b, o in zip(builds, outs):
             b.run(d, img.data_ptr(), o.data_ptr())
+            b.lib.ss_ctx_sync(b.ctx)
     torch.cuda.synchronize()
     # results of the builds against the first (bytes that differ)
     for b, o in zip(builds[1:], outs[1:]):
@@ -89,7 +91,15 @@ def main():
         y = o.view(torch.uint8).flatten()[:n]
         step = 1 << 30  # (comparisons of more than 2^32 elements at once came back wrong on this torch build)
         diff = sum(int((x[i:i + step] != y[i:i + step]).sum()) for i in range(0, n, step))
-        print(f"{os.path.basename(b.path)}: {diff} of {n} output bytes differ from {os.path.basename(builds[0].path)}")
+        line = f"{os.path.basename(b.path)}: {diff} of {n} output bytes differ from {os.path.basename(builds[0].path)}"
+        if a.config.startswith("2") and diff:
+            m = 0
+            for i in range(0, n // 2, step):
+                xa = outs[0].view(torch.int16).flatten()[i:i + step].to(torch.int32) & 0xFFFF
+                ya = o.view(torch.int16).flatten()[i:i + step].to(torch.int32) & 0xFFFF
+                m = max(m, int((xa - ya).abs().max()))
+            line += f" (largest difference {m} steps of 16 bits)"
+        print(line)
     ts = [[] for _ in builds]
     for r in range(a.rounds):
         order = list(range(len(builds)))
