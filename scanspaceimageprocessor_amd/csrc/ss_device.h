@@ -906,10 +906,13 @@ __device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const
   V dfx = dfy, dfz = dfy;
   const bool chroma = CHROMA < 0 ? P.usm_chroma != 0 : CHROMA != 0;
   if (chroma) {
-    const V boost = mad<V>(vabs(um), P.usm_chroma_k, 1.0f);
-    const V a = (f.fx - f.fy) * 500.0f, b = (f.fy - f.fz) * 200.0f;
-    dfx = mad<V>(clampf(a * boost, -127.0f, 127.0f) - a, 1.0f / 500.0f, dfy);
-    dfz = mad<V>(clampf(b * boost, -127.0f, 127.0f) - b, -1.0f / 200.0f, dfy);
+    // clip(a (1 + e), -127, 127) - a = med3(a e, -127 - a, 127 - a), in units of fx - fy = a / 500 and
+    // fy - fz = b / 200.  Formed as a difference: for a small edit 1 + e rounds to 1 or 1 + 2^-23 and a (1 + e) to a
+    // multiple of 8e-6, which moved a dark channel of a saturated pixel by 1e-7.
+    const V e = vabs(um) * P.usm_chroma_k;
+    const V pa = f.fx - f.fy, pb = f.fy - f.fz;
+    dfx = dfy + med3(pa * e, (V)(-127.0f / 500.0f) - pa, (V)(127.0f / 500.0f) - pa);
+    dfz = dfy - med3(pb * e, (V)(-127.0f / 200.0f) - pb, (V)(127.0f / 200.0f) - pb);
   }
   // one d for X, Y and Z and a pixel in [0, 1]: |d| <= floor / 4 keeps every |g(f + d) - g(f)| below the floor
   // (3 (1.0001 + d)^2 d <= 0.91 floor for floor <= 0.4)

@@ -287,7 +287,7 @@ def test_committed_bench_line_names_the_committed_counter_summary():
     import json
 
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    line = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
+    line = json.load(open(os.path.join(root, "profiles", "r03_bench_line.json")))
     roof = line["roofline"]
     raw = open(os.path.join(root, roof["pmc_file"]), "rb").read()
     assert hashlib.sha256(raw).hexdigest() == roof["pmc_sha256"]
@@ -298,3 +298,29 @@ def test_committed_bench_line_names_the_committed_counter_summary():
     for name in pmc["sources"]:
         assert os.path.exists(os.path.join(root, "profiles", name))
     assert {"threads4", "threads_all"} <= set(line["cpu_baseline"]) and len(line["others"]) >= 3
+    # the vector-ALU figures are priced per instruction class from the same file: a fraction, and its complement
+    assert roof["valu_mix_per_px"] == pmc["valu_mix"] and 0.0 < roof["valu_frac"] <= 1.0
+    assert abs(roof["valu_frac"] + roof["valu_stall_frac"] - 1.0) < 2e-4
+    assert abs(roof["valu_frac"] - roof["valu_priced_cycles_per_64px"] / roof["valu_cycles_per_64px"]) < 1e-3
+
+
+def test_design_quotes_the_committed_bench_line():
+    """DESIGN.md's measurement section quotes value, kernel_ms and frac of the committed line: they must be its."""
+    import json
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    line = json.load(open(os.path.join(root, "profiles", "r03_bench_line.json")))
+    text = open(os.path.join(root, "DESIGN.md")).read()
+    m = re.search(r"Round 3 line \(`profiles/r03_bench_line\.json`\)[^\n]*", text)
+    assert m, "DESIGN.md must quote the round-3 bench line"
+    quoted = m.group(0)
+
+    def number(label):
+        mm = re.search(label + r"\D{0,12}?([0-9][0-9,]*\.?[0-9]*)", quoted)
+        assert mm, (label, quoted)
+        return float(mm.group(1).replace(",", ""))
+
+    assert abs(number("`value`") - line["value"]) <= 0.5
+    assert abs(number("`kernel_ms`") - line["roofline"]["kernel_ms"]) <= 5e-4
+    assert abs(number("`frac`") - line["roofline"]["frac"]) <= 5e-4

@@ -36,11 +36,13 @@ def main():
             if out in ("u16", "u8"):
                 scale = 65535.0 if out == "u16" else 255.0
                 diff = np.abs(got[i].astype(np.int64) - want.astype(np.int64))
-                extra = tp._blur_allowance(want / scale, usm[0], True) * scale if usm is not None else 0.0
+                extra = 0.0
+                if usm is not None:
+                    extra = tp._blur_allowance(lambda: tp._oracle_chain(imgs[i], M_T, M_R, *recipe[:-1], "f32_srgb") * scale)
                 over = diff - (1 + np.floor(tp.F32_TOL * scale + extra))
             else:
                 err = np.abs(got[i] - want)
-                extra = tp._blur_allowance(want, usm[0], out == "f32_srgb") if usm is not None else 0.0
+                extra = tp._blur_allowance(lambda: tp._oracle_chain(imgs[i], M_T, M_R, *recipe)) if usm is not None else 0.0
                 over = (err - (tp.F32_TOL + extra)) / tp.F32_TOL
             bad = max(bad, float(np.max(over)))
         if bad > 0:
