@@ -158,7 +158,9 @@ const char* ss_version(void);
  * A colour correction whose coefficients float32 cannot carry - the sum over its terms of the largest
  * |coefficient| above 8, which on 24 swatches means 22 polynomial terms or a root-polynomial of degree 3 or 4 - is
  * evaluated in float64 for every pixel (colour.colour_correction works in float64, imageProcessorWorker.py:337):
- * a pass of its own into a float32 staging image owned by the context, the rest of the chain from there.
+ * a pass of its own that finishes the chain when only gains, the final clip and the output encoding follow, and
+ * otherwise (shadows / highlights or an unsharp mask behind it) writes a float32 staging image owned by the context,
+ * from which the rest of the chain runs.
  * Replaces, for one batch: ImageCorrectionWorker.run steps 5-7 (imageProcessorWorker.py:855-923),
  * apply_all_adjustments (editingTools.py:823-909) and its callees. */
 int ss_chain_run(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev);
@@ -213,8 +215,8 @@ int ss_chain_requeued(ss_ctx* ctx, uint64_t* n_pixels);
  * Limits: a chain with a Lab edit and a float32 or 16-bit output may cover about 134 million pixels per call (the
  * record's 16 MiB; beyond: SS_ERR_UNSUPPORTED); the combination "unsharp mask behind a colour correction of more
  * than 3 terms" needs a staging image per image of the batch and is refused (SS_ERR_UNSUPPORTED: use
- * ss_chain_run), and so does a colour correction that is evaluated in float64 (see ss_chain_run) with any stage or
- * output encoding behind it; the batch may hold at most 2^31 - 1 tiles of 128 x 24 pixels.  Asynchronous. */
+ * ss_chain_run), and so does a colour correction that is evaluated in float64 (see ss_chain_run) with shadows /
+ * highlights behind it; the batch may hold at most 2^31 - 1 tiles of 128 x 24 pixels.  Asynchronous. */
 int ss_chain_run_static(ss_ctx* ctx, const ss_chain_desc* desc, const float* src_dev, void* dst_dev);
 
 /* ---- negative film mode: per-channel percentiles ------------------------------------------ */

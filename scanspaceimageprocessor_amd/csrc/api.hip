@@ -443,13 +443,17 @@ size_t chain_stage_bytes() {
 // C = sum over the terms of the largest |coefficient| of the term, and float32 keeps the channel to ~4e-7 C.  Held
 // against a third of the 1e-5 the result is compared at: C > 8.  (Fits of up to ~20 polynomial terms on 24 swatches stay
 // well below that; 22 terms and the root-polynomials of degree 3 and 4 have coefficients of 10 ... 10^5.)
-bool ccm_needs_f64(const ChainParams& P) {
-  if (P.ccm_kind == SS_CCM_NONE || P.ccm_terms <= 3) return false;
-  static const bool never = [] {  // SS_CCM_F64=0: a debugging aid (float32 throughout)
+bool f64_pass_disabled() {  // SS_CCM_F64=0: a debugging aid (float32 throughout)
+  static const bool never = [] {
     const char* v = getenv("SS_CCM_F64");
     return v && v[0] == '0';
   }();
-  if (never) return false;
+  return never;
+}
+
+bool ccm_needs_f64(const ChainParams& P) {
+  if (P.ccm_kind == SS_CCM_NONE || P.ccm_terms <= 3) return false;
+  if (f64_pass_disabled()) return false;
   double bound = 0.0;
   for (int t = 0; t < P.ccm_terms; ++t) {
     double m = 0.0;
@@ -459,20 +463,24 @@ bool ccm_needs_f64(const ChainParams& P) {
   return 4.0e-7 * bound > 1.0e-5 / 3.0;
 }
 
-// nothing behind stages 1-2: their float32 result is the call's output
-bool chain_ends_behind_ccm(const ChainParams& P, int out_kind) {
-  return !P.usm && !P.sh && P.n_gain == 0 && !P.final_clip && !P.lab_io && out_kind == SS_OUT_F32_LINEAR && !P.dst2;
-}
+// Nothing but gains, the final clip and the output encoding behind stages 1-2: the float64 pass finishes the chain
+// itself (no staging image, one launch).
+bool f64_pass_finishes_chain(const ChainParams& P) { return !P.usm && !P.sh && !P.lab_io; }
 
 // Two launches per group of images through a float32 staging image: {negative inversion, colour correction}, then
 // everything behind them from the staged pixels.  Used for an unsharp mask behind a colour correction of more than 3
 // terms, and for every chain whose colour correction takes the float64 pass.
 int run_staged(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, const float* src_dev, void* dst_dev,
                const ChainScratch& S) {
-  const bool dense = ccm_needs_f64(P);
+  // In front of an unsharp mask every correction of more than 3 terms takes the float64 pass: the stage blurs the
+  // lightness of what it is handed, and amount / 50 times a few 1e-7 of float32 rounding in 14 or 20 products per
+  // pixel, through two sRGB encodes, is more than the result may differ by on the dark channel of a saturated pixel
+  // (one unit in the last place of the lightness moves such a value by 1e-5 at amount 80).  The staging image then
+  // holds the correction's float64 value rounded once.
+  const bool dense = ccm_needs_f64(P) || (P.usm && P.ccm_kind != SS_CCM_NONE && P.ccm_terms > 3 && !f64_pass_disabled());
   const size_t image_bytes = (size_t)P.n_px * 3 * sizeof(float);
-  if (dense && chain_ends_behind_ccm(P, d->out_kind)) {
-    const hipError_t e = launch_ccm_f64(P, d->batch, src_dev, (float*)dst_dev, c->stream);
+  if (dense && f64_pass_finishes_chain(P)) {
+    const hipError_t e = launch_ccm_f64(P, d->batch, src_dev, dst_dev, d->out_kind, c->stream);
     if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return SS_OK;
   }
@@ -501,7 +509,7 @@ int run_staged(ss_ctx* c, const ss_chain_desc* d, const ChainParams& P, const fl
     A.dst2 = nullptr;  // the second output is made where the first is
     if (B.dst2) B.dst2 += (size_t)first * P.n_px * 3;
     if (dense) {
-      const hipError_t e = launch_ccm_f64(A, n, src_dev + (size_t)first * P.n_px * 3, (float*)c->ws_stage, c->stream);
+      const hipError_t e = launch_ccm_f64(A, n, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, -1, c->stream);
       if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     } else {
       rc = launch_chain_and_careful(c, A, n, SS_OUT_F32_LINEAR, src_dev + (size_t)first * P.n_px * 3, c->ws_stage, S);
@@ -686,12 +694,13 @@ int ss_chain_run_static(ss_ctx* c, const ss_chain_desc* d, const float* src_dev,
                 "batch, which the static scratch of ss_chain_run_static does not hold: use ss_chain_run",
                 P.ccm_terms);
   if (ccm_needs_f64(P)) {
-    if (!chain_ends_behind_ccm(P, d->out_kind))
+    if (!f64_pass_finishes_chain(P))
       return fail(c, SS_ERR_UNSUPPORTED,
-                  "this %d-term colour correction is evaluated in float64 into a float32 staging image per image of "
-                  "the batch, which the static scratch of ss_chain_run_static does not hold: use ss_chain_run",
+                  "this %d-term colour correction is evaluated in float64, and with shadows / highlights behind it "
+                  "that pass writes a float32 staging image per image of the batch, which the static scratch of "
+                  "ss_chain_run_static does not hold: use ss_chain_run",
                   P.ccm_terms);
-    const hipError_t e = launch_ccm_f64(P, d->batch, src_dev, (float*)dst_dev, c->stream);
+    const hipError_t e = launch_ccm_f64(P, d->batch, src_dev, dst_dev, d->out_kind, c->stream);
     if (e != hipSuccess) return fail(c, SS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return SS_OK;
   }

@@ -279,21 +279,35 @@ hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const flo
 // float32 as the reference does it, expansion and sum in float64 with the coefficients' float64 values
 // (ccm_full + ccm_lo), the result rounded to float32 (unclipped linear RGB) for the stages behind it.
 // One trip of 1024 pixels per workgroup, lane t taking pixels t, t + 256, ... like the pointwise chain.
+// `out_kind` < 0: the result goes to `dst` as it is (a float32 staging image for the kernels of the stages behind).
+// `out_kind` >= 0: nothing but gains, the final clip and the output encoding are behind the correction, and the pass
+// finishes the chain itself - the same float32 operations in the same order as the pointwise kernel applies to a
+// staged pixel, so both routes give the same bits - and stores in the output's format (and the 8-bit second
+// output, when the call has one), a pixel per lane.
 // (KIND, T: the expansion, compile-time so that the terms live in registers)
+template <int OUT>
+__device__ __forceinline__ void finish_and_store(const Px v, const ChainParams& P, void* dst_img, uint32_t px) {
+  store_one<OUT>(dst_img, px, finish<OUT, false, float>(v, P));
+}
+
+// The coefficients' float64 values, [channel][term]: the kernel's second argument.  The products take them as
+// scalar operands, loaded from the kernel-argument segment next to their uses (66 values are 132 scalar registers:
+// more than the file holds, so they are fetched again for every pixel through a pointer the compiler cannot see
+// through; as LDS reads they kept the LDS pipe as busy as the float64 unit).
+struct F64Coefs {
+  double c[3][SS_MAX_CCM_TERMS];
+};
+
 template <int KIND, int T>
-__global__ __launch_bounds__(256) void ccm_f64_kernel(const ChainParams P, const float* __restrict__ src,
-                                                      float* __restrict__ dst) {
-  __shared__ double coef[T][3];
-  for (int i = threadIdx.x; i < T * 3; i += 256) {
-    const int t = i / 3, ch = i - t * 3;
-    coef[t][ch] = (double)P.ccm_full[t][ch] + (double)P.ccm_lo[t][ch];
-  }
-  __syncthreads();
+__global__ __launch_bounds__(256) void ccm_f64_kernel(const ChainParams P, const F64Coefs C_arg,
+                                                      const float* __restrict__ src, void* __restrict__ dst, int out_kind) {
   const int img = blockIdx.y;
   const ImgParams ip = load_img_params(P, img);
   const uint32_t n = (uint32_t)P.n_px;
   const F3* __restrict__ s = reinterpret_cast<const F3*>(src + (size_t)img * n * 3);
-  F3* __restrict__ d = reinterpret_cast<F3*>(dst + (size_t)img * n * 3);
+  const size_t out_px_bytes = out_kind < 0 || out_kind == SS_OUT_F32_LINEAR || out_kind == SS_OUT_F32_SRGB
+                                  ? 12 : (out_kind == SS_OUT_U16_SRGB ? 6 : 3);
+  char* d = reinterpret_cast<char*>(dst) + (size_t)img * n * out_px_bytes;
   for (uint32_t base = blockIdx.x * 1024u; base < n; base += gridDim.x * 1024u) {
     F3 in[4] = {};
 #pragma unroll
@@ -312,26 +326,53 @@ __global__ __launch_bounds__(256) void ccm_f64_kernel(const ChainParams P, const
       }
       double e[SS_MAX_CCM_TERMS];
       careful::expand_shared_roots(KIND, T, (double)x[0], (double)x[1], (double)x[2], e);
+      typedef const __attribute__((address_space(4))) F64Coefs* KernargCoefs;
+      KernargCoefs kc = (KernargCoefs)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                       ((sizeof(ChainParams) + 7) & ~(size_t)7));
       double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+      asm volatile("" : "+s"(kc));
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        o0 += coef[t][0] * e[t];
-        o1 += coef[t][1] * e[t];
-        o2 += coef[t][2] * e[t];
+      for (int t = 0; t < T; ++t) o0 = fma(kc->c[0][t], e[t], o0);
+#pragma unroll
+      for (int t = 0; t < T; ++t) o1 = fma(kc->c[1][t], e[t], o1);
+#pragma unroll
+      for (int t = 0; t < T; ++t) o2 = fma(kc->c[2][t], e[t], o2);
+      if (p >= n) continue;
+      Px v{(float)o0, (float)o1, (float)o2};
+      if (out_kind < 0) {
+        store_stream(reinterpret_cast<F3*>(d) + p, F3{v.r, v.g, v.b});
+        continue;
       }
-      if (p < n) store_stream(d + p, F3{(float)o0, (float)o1, (float)o2});
+      if (P.n_gain > 0) {
+        v = Px{clamp01(v.r * ip.gain0[0]), clamp01(v.g * ip.gain0[1]), clamp01(v.b * ip.gain0[2])};
+        if (P.n_gain > 1) {
+          v = Px{clamp01(v.r * P.gain[1][0]), clamp01(v.g * P.gain[1][1]), clamp01(v.b * P.gain[1][2])};
+          if (P.n_gain > 2) v = Px{clamp01(v.r * P.gain[2][0]), clamp01(v.g * P.gain[2][1]), clamp01(v.b * P.gain[2][2])};
+        }
+      }
+      if (P.dst2 != nullptr) store_second(P.dst2, (size_t)img * n + p, v, P.final_clip != 0, P.dst2_encoded != 0);
+      switch (out_kind) {
+        case SS_OUT_F32_LINEAR: finish_and_store<SS_OUT_F32_LINEAR>(v, P, d, p); break;
+        case SS_OUT_F32_SRGB: finish_and_store<SS_OUT_F32_SRGB>(v, P, d, p); break;
+        case SS_OUT_U16_SRGB: finish_and_store<SS_OUT_U16_SRGB>(v, P, d, p); break;
+        case SS_OUT_U8_SRGB: finish_and_store<SS_OUT_U8_SRGB>(v, P, d, p); break;
+        default: finish_and_store<SS_OUT_U8_LINEAR>(v, P, d, p); break;
+      }
     }
   }
 }
 
-hipError_t launch_ccm_f64(const ChainParams& P, int batch, const float* src, float* dst, hipStream_t st) {
+hipError_t launch_ccm_f64(const ChainParams& P, int batch, const float* src, void* dst, int out_kind, hipStream_t st) {
   uint64_t blocks = ((uint64_t)P.n_px + 1023) / 1024;
   if (blocks < 1) blocks = 1;
   if (blocks > 32768) blocks = 32768;
   const dim3 grid((unsigned)blocks, (unsigned)batch, 1);
+  F64Coefs C{};
+  for (int t = 0; t < P.ccm_terms; ++t)
+    for (int ch = 0; ch < 3; ++ch) C.c[ch][t] = (double)P.ccm_full[t][ch] + (double)P.ccm_lo[t][ch];
 #define SS_F64_CASE(KIND, T)                                                                          \
   if (P.ccm_kind == KIND && P.ccm_terms == T) {                                                       \
-    hipLaunchKernelGGL((ccm_f64_kernel<KIND, T>), grid, dim3(256), 0, st, P, src, dst);               \
+    hipLaunchKernelGGL((ccm_f64_kernel<KIND, T>), grid, dim3(256), 0, st, P, C, src, dst, out_kind);  \
     return hipGetLastError();                                                                         \
   }
   SS_F64_CASE(SS_CCM_CHEUNG, 5) SS_F64_CASE(SS_CCM_CHEUNG, 7) SS_F64_CASE(SS_CCM_CHEUNG, 8) SS_F64_CASE(SS_CCM_CHEUNG, 10)

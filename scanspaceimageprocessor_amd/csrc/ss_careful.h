@@ -203,9 +203,34 @@ __device__ __forceinline__ int expand(int kind, int terms, double R, double G, d
   return n;
 }
 
+// sign(a) |a|^(1/M) for the dense float64 colour-correction pass: the float32 hardware estimate (sqrt, or
+// exp2(log2 |a| / M)), good to 1e-7 relative, and STEPS Newton steps on y^M = |a| in float64.  A step squares the
+// error ((M - 1)/2 e^2) and its quotient (y^M - |a|) / (M y^(M-1)) is of size e, so the float32 reciprocal of the
+// denominator serves (it adds e * 1e-7): one step leaves ~1e-14, two are as good as float64 gets.  A third of the
+// instructions of sqrt() / pow(), and no float64 transcendental (quarter rate).  |a| below float32's range
+// (1e-38, where the hardware estimates flush to 0) gives 0: an absolute error of at most 1e-19 on a term.
+template <int M, int STEPS>
+__device__ __forceinline__ double sroot(double a) {
+  const double x = fabs(a);
+  const float xf = (float)x;
+  const double y0 = (double)(M == 2 ? __builtin_amdgcn_sqrtf(xf)
+                                    : __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (1.0f / (float)M)));
+  double y = y0;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const double ym1 = ipow<M - 1>(y);
+    // (estimate 0: the reciprocal is inf and the step NaN; selected away below)
+    y -= (ym1 * y - x) * (double)__builtin_amdgcn_rcpf((float)M * (float)ym1);
+  }
+  y = y0 == 0.0 ? 0.0 : y;
+  return a < 0.0 ? -y : y;
+}
+
 // The same term lists for the dense float64 colour-correction pass: the root-polynomial terms as products of the
 // three channels' own signed roots (sign(x y) |x y|^p = spow(x, p) spow(y, p): three square, cube and fourth roots
 // instead of three, seven and nine), which in float64 agree with the roots of the products to a few 1e-16.
+// Degree 4 takes two Newton steps per root (its fits have coefficients of 10^5: 1e-14 on a term would show as 1e-9
+// in the pixel, harmless, but the terms of a fit that bad deserve every bit), the others one.
 __device__ __forceinline__ int expand_shared_roots(int kind, int terms, double R, double G, double B, double e[SS_MAX_CCM_TERMS]) {
   if (kind != SS_CCM_ROOTPOLY || terms <= 3) return expand(kind, terms, R, G, B, e);
   int n = 0;
@@ -213,33 +238,36 @@ __device__ __forceinline__ int expand_shared_roots(int kind, int terms, double R
   e[n++] = G;
   e[n++] = B;
   if (terms == 6) {
-    const double hr = sroot2(R), hg = sroot2(G), hb = sroot2(B);
+    const double hr = sroot<2, 1>(R), hg = sroot<2, 1>(G), hb = sroot<2, 1>(B);
     e[n++] = hr * hg;
     e[n++] = hg * hb;
     e[n++] = hr * hb;
     return n;
   }
-  // (a second Newton step: coefficients of 10^5 multiply these, and rpow's 1e-12 would show as 1e-7 in the pixel;
-  // the step is of size 1e-12 itself, so the float32 reciprocal of its denominator serves, as in rpow)
-  auto cube_root = [](double x) -> double {
-    const double y = rpow<1, 3>(x);
-    if (y == 0.0) return 0.0;
-    return y - (y * y * y - x) * (double)__builtin_amdgcn_rcpf(3.0f * (float)(y * y));
-  };
-  const double cr = cube_root(R), cg = cube_root(G), cb = cube_root(B);
-  const double cr2 = cr * cr, cg2 = cg * cg, cb2 = cb * cb;
   if (terms == 13) {
-    const double hr = sroot2(R), hg = sroot2(G), hb = sroot2(B);
+    const double hr = sroot<2, 1>(R), hg = sroot<2, 1>(G), hb = sroot<2, 1>(B);
+    const double cr = sroot<3, 1>(R), cg = sroot<3, 1>(G), cb = sroot<3, 1>(B);
+    const double cr2 = cr * cr, cg2 = cg * cg, cb2 = cb * cb;
     e[n++] = hr * hg;
     e[n++] = hg * hb;
     e[n++] = hr * hb;
-  } else {
-    const double qr = sroot4(R), qg = sroot4(G), qb = sroot4(B);             // signed fourth roots
-    const double hr = qr * fabs(qr), hg = qg * fabs(qg), hb = qb * fabs(qb);  // signed square roots
-    e[n++] = hr * hg;
-    e[n++] = hg * hb;
-    e[n++] = hr * hb;
+    e[n++] = cr * cg2;
+    e[n++] = cg * cb2;
+    e[n++] = cr * cb2;
+    e[n++] = cg * cr2;
+    e[n++] = cb * cg2;
+    e[n++] = cb * cr2;
+    e[n++] = (cr * cg) * cb;
+    return n;
   }
+  const double cr = sroot<3, 2>(R), cg = sroot<3, 2>(G), cb = sroot<3, 2>(B);
+  const double cr2 = cr * cr, cg2 = cg * cg, cb2 = cb * cb;
+  const double qr = sroot<4, 2>(R), qg = sroot<4, 2>(G), qb = sroot<4, 2>(B);  // signed fourth roots
+  const double ar = qr * qr, ag = qg * qg, ab = qb * qb;                       // |x|^(1/2)
+  const double hr = qr * fabs(qr), hg = qg * fabs(qg), hb = qb * fabs(qb);     // signed square roots
+  e[n++] = hr * hg;
+  e[n++] = hg * hb;
+  e[n++] = hr * hb;
   e[n++] = cr * cg2;
   e[n++] = cg * cb2;
   e[n++] = cr * cb2;
@@ -247,9 +275,6 @@ __device__ __forceinline__ int expand_shared_roots(int kind, int terms, double R
   e[n++] = cb * cg2;
   e[n++] = cb * cr2;
   e[n++] = (cr * cg) * cb;
-  if (terms == 13) return n;
-  const double qr = sroot4(R), qg = sroot4(G), qb = sroot4(B);
-  const double ar = qr * qr, ag = qg * qg, ab = qb * qb;  // |x|^(1/2)
   e[n++] = (ar * qr) * qg;  // (R^3 G)^(1/4)
   e[n++] = (ar * qr) * qb;
   e[n++] = (ag * qg) * qr;

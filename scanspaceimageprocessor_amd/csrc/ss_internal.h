@@ -17,8 +17,10 @@ bool chain_needs_careful(const ChainParams& P, int out_kind);
 // float64 re-evaluation of what the launch before it recorded (same P, batch, src, dst), overwriting those output
 // pixels; the record's layout follows from P.usm (tile kernel) or not (pointwise kernel)
 hipError_t launch_careful(const ChainParams& P, int batch, int out_kind, const float* src, void* dst, hipStream_t st);
-// stages 1-2 of every pixel with the colour correction in float64 -> float32 linear RGB (see ccm_f64_kernel)
-hipError_t launch_ccm_f64(const ChainParams& P, int batch, const float* src, float* dst, hipStream_t st);
+// stages 1-2 of every pixel with the colour correction in float64 (see ccm_f64_kernel): out_kind < 0 -> float32 linear
+// RGB for the stages behind; out_kind >= 0 (chains with nothing but gains, the final clip and the encoding behind the
+// correction) -> the chain's output
+hipError_t launch_ccm_f64(const ChainParams& P, int batch, const float* src, void* dst, int out_kind, hipStream_t st);
 // Fused chain with the unsharp mask (stage 5): tile + halo recompute, separable blur in LDS.
 // Colour correction: none or the 3-term matrix only (callers run larger expansions as a pointwise pass first).
 // `ticket`: eight uint32 of device memory owned by the caller (the per-XCD segment counters); launches that share

@@ -410,6 +410,24 @@ def test_usm_behind_larger_colour_corrections(swatches, monkeypatch, stage_bytes
         assert np.max(np.abs(got[i] - want)) <= F32_TOL
 
 
+@pytest.mark.parametrize("out", ["f32", "f32_srgb", "u16", "u8"])
+@pytest.mark.parametrize("method,kw", [("Cheung 2004", {"terms": 22}), ("Finlayson 2015", {"degree": 3}),
+                                       ("Finlayson 2015", {"degree": 4})])
+def test_float64_colour_correction_finishes_simple_chains_itself(swatches, method, kw, out):
+    """With only gains, the final clip and the encoding behind it, the float64 colour-correction pass stores the
+    chain's output itself (one launch, no staging image).  Its tail is the pointwise kernel's arithmetic, so the
+    result is, bit for bit, the bare correction (float32, unclipped) followed by a chain without a correction."""
+    M_T, M_R = swatches
+    imgs = np.stack([inputs.linear_image(310 + i, 37, 1031) for i in range(2)])  # 1031: a ragged last trip
+    ccm = fit(M_T, M_R, method=method, **kw)
+    gains = [np.array([1.1, 0.9, 1.2]), 0.8]
+    one = run_chain_dev(imgs, ccm=ccm, gains=gains, final_clip=True, out=out)
+    bare = run_chain_dev(imgs, ccm=ccm, gains=[], out="f32")
+    two = run_chain_dev(bare, gains=gains, final_clip=True, out=out)
+    assert np.array_equal(one.view(np.uint8), two.view(np.uint8))
+    assert one.any()
+
+
 @pytest.mark.parametrize("radius", [1.0, 2.0])
 def test_no_chart_path_all_adjustments(radius):
     """The worker's no-chart path: exposure, shadows/highlights and sharpen with no colour correction."""
@@ -566,8 +584,15 @@ def _oracle_chain(img, M_T, M_R, neg, ccm_kw, gains, sh, usm, final_clip, out):
     """The stages of a descriptor composed from the oracle's functions, in the kernel's stage order."""
     x = img.astype(np.float64)
     if neg is not None:
-        lo, inv = neg
-        x = 1.0 - np.clip((np.clip(x, 0, 1) - np.asarray(lo, np.float64)) * np.asarray(inv, np.float64), 0, 1)
+        # Stage 1 as the descriptor defines it (include/scanspace.h: float32 parameters, float32 subtraction and
+        # product, the reference's invert_negative_auto under numpy >= 2 up to its division): every operation is a
+        # single IEEE rounding, so these are the kernel's inverted values bit for bit, and everything behind them
+        # is held to float64.  (What the inversion itself may differ by from the reference's two arithmetics is
+        # the subject of the negative-mode tests, not of this one: a chain that cancels a channel amplifies one
+        # unit in the last place of an inverted value a thousandfold.)
+        lo, inv = (np.asarray(v, np.float32) for v in neg)
+        q = np.clip((np.clip(img.astype(np.float32), np.float32(0), np.float32(1)) - lo) * inv, np.float32(0), np.float32(1))
+        x = (np.float32(1.0) - q).astype(np.float64)
     if ccm_kw is not None:
         x = lv.colour_correction(x, M_T, M_R, **ccm_kw)
     for g in gains:

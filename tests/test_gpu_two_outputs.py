@@ -26,6 +26,8 @@ def _chains():
         "sh_usm": dict(ccm=lin3, gains=[1.1], sh=(-0.3, 0.6, 5.0), usm=(45.0, 2.0, 1.0), final_clip=True),
         "usm_runtime_radius": dict(ccm=lin3, gains=[1.0], usm=(30.0, 4.0, 0.0), final_clip=True),
         "staged": dict(ccm=root3, gains=[1.1], usm=(80.0, 2.0, 0.0), final_clip=True),
+        "dense_f64": dict(ccm=root3, gains=[1.1, 0.95], final_clip=True),  # the float64 pass finishes the chain itself
+        "dense_f64_sh": dict(ccm=root3, gains=[1.1], sh=(0.4, -0.5, 7.0), final_clip=True),  # ... and stages it here
         "neg": dict(neg=([0.05, 0.04, 0.03], [1.2, 1.3, 1.4]), ccm=lin3, final_clip=True),
     }
 

@@ -43,24 +43,27 @@ def test_static_entry_point_matches_chain_run_twice_in_a_row():
     ctx = default_context()
     M_T, M_R = _swatches()
     ccm = fit(M_T, M_R)
+    root3 = fit(M_T, M_R, method="Finlayson 2015", degree=3)  # evaluated in float64 for every pixel
     rng = np.random.default_rng(5)
     big = (rng.random((3, 301, 517, 3)) ** 2.2 * 0.9).astype(np.float32)
     small = (rng.random((1, 97, 150, 3)) ** 2.2 * 0.9).astype(np.float32)
     for images in (big, small):
         for kw in (dict(ccm=ccm, gains=[1.1], usm=(1.0, 2.0, 0.0), final_clip=True, out="u16"),
                    dict(ccm=ccm, gains=[0.9], sh=(0.5, -0.5, 7.0), usm=(50.0, 1.0, 2.0), final_clip=True, out="f32_srgb"),
-                   dict(ccm=ccm, gains=[1.0], final_clip=True, out="f32_srgb")):
+                   dict(ccm=ccm, gains=[1.0], final_clip=True, out="f32_srgb"),
+                   dict(ccm=root3, gains=[1.05], final_clip=True, out="u16")):
             ref, got = _both(ctx, images, **kw)
             assert np.array_equal(ref, got)
             assert ref.any()
 
 
-def test_static_entry_point_refuses_what_needs_a_staging_buffer():
+@pytest.mark.parametrize("behind", [dict(usm=(10.0, 1.0, 0.0)), dict(gains=[1.0], sh=(0.5, -0.5, 7.0))])
+def test_static_entry_point_refuses_what_needs_a_staging_buffer(behind):
     ctx = default_context()
     M_T, M_R = _swatches()
     ccm = fit(M_T, M_R, method="Finlayson 2015", degree=3)
     img = np.full((1, 32, 40, 3), 0.25, np.float32)
-    desc = make_desc(32, 40, 1, ccm=ccm, usm=(10.0, 1.0, 0.0), out="u16")
+    desc = make_desc(32, 40, 1, ccm=ccm, out="u16", **behind)
     src = DeviceBuffer.from_array(ctx, img)
     dst = DeviceBuffer(ctx, img.size * 2)
     try:
