@@ -272,19 +272,7 @@ hipError_t launch_chain(const ChainParams& P, int batch, int out_kind, const flo
 // dense float64 colour correction (stages 1-2 of every pixel), for coefficient tables float32 cannot carry
 // ------------------------------------------------------------------------------------------------
 
-// A fit with nearly as many terms as swatches (22 terms, root-polynomials of degree 3 and 4 on 24 swatches) has
-// coefficients of size 10 ... 10^5 whose products with the terms cancel to a pixel of size 1: float32 keeps such a
-// sum to ~4e-7 of the sum of |coefficient x term|, several times the 1e-5 the result is held to.  The reference
-// evaluates it in float64 (colour_correction converts its input first); so does this pass: negative inversion in
-// float32 as the reference does it, expansion and sum in float64 with the coefficients' float64 values
-// (ccm_full + ccm_lo), the result rounded to float32 (unclipped linear RGB) for the stages behind it.
-// One trip of 1024 pixels per workgroup, lane t taking pixels t, t + 256, ... like the pointwise chain.
-// `out_kind` < 0: the result goes to `dst` as it is (a float32 staging image for the kernels of the stages behind).
-// `out_kind` >= 0: nothing but gains, the final clip and the output encoding are behind the correction, and the pass
-// finishes the chain itself - the same float32 operations in the same order as the pointwise kernel applies to a
-// staged pixel, so both routes give the same bits - and stores in the output's format (and the 8-bit second
-// output, when the call has one), a pixel per lane.
-// (KIND, T: the expansion, compile-time so that the terms live in registers)
+// stages 6-7 of one pixel and its store, as the pointwise kernel does them
 template <int OUT>
 __device__ __forceinline__ void finish_and_store(const Px v, const ChainParams& P, void* dst_img, uint32_t px) {
   store_one<OUT>(dst_img, px, finish<OUT, false, float>(v, P));
@@ -293,11 +281,25 @@ __device__ __forceinline__ void finish_and_store(const Px v, const ChainParams& 
 // The coefficients' float64 values, [channel][term]: the kernel's second argument.  The products take them as
 // scalar operands, loaded from the kernel-argument segment next to their uses (66 values are 132 scalar registers:
 // more than the file holds, so they are fetched again for every pixel through a pointer the compiler cannot see
-// through; as LDS reads they kept the LDS pipe as busy as the float64 unit).
+// through; as LDS reads they kept the LDS pipe as busy as the float64 unit).  The launcher fills it from
+// ccm_full + ccm_lo.
 struct F64Coefs {
   double c[3][SS_MAX_CCM_TERMS];
 };
 
+// A fit with nearly as many terms as swatches (22 terms, root-polynomials of degree 3 and 4 on 24 swatches) has
+// coefficients of size 10 ... 10^5 whose products with the terms cancel to a pixel of size 1: float32 keeps such a
+// sum to ~4e-7 of the sum of |coefficient x term|, several times the 1e-5 the result is held to.  The reference
+// evaluates it in float64 (colour_correction converts its input first); so does this pass: negative inversion in
+// float32 as the reference does it, expansion and sum in float64 with the coefficients' float64 values,
+// the result rounded to float32 (unclipped linear RGB) for the stages behind it.
+// One trip of 1024 pixels per workgroup, lane t taking pixels t, t + 256, ... like the pointwise chain.
+// `out_kind` < 0: the result goes to `dst` as it is (a float32 staging image for the kernels of the stages behind).
+// `out_kind` >= 0: nothing but gains, the final clip and the output encoding are behind the correction, and the pass
+// finishes the chain itself - the same float32 operations in the same order as the pointwise kernel applies to a
+// staged pixel, so both routes give the same bits - and stores in the output's format (and the 8-bit second
+// output, when the call has one), a pixel per lane.
+// (KIND, T: the expansion, compile-time so that the terms live in registers)
 template <int KIND, int T>
 __global__ __launch_bounds__(256) void ccm_f64_kernel(const ChainParams P, const F64Coefs C_arg,
                                                       const float* __restrict__ src, void* __restrict__ dst, int out_kind) {
