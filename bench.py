@@ -417,8 +417,9 @@ def main():
                          timed(lambda: ctx.chain_run(d4, img4.data_ptr(), out4.data_ptr()))))
         ccm4b = matrix_colour_correction(M_T, M_R, method="Finlayson 2015", degree=3)
         d4b = make_desc(H4, W4, B4, ccm=ccm4b, gains=[1.0], sh=(0.5, -0.5, 7.0), final_clip=True, out="f32")
-        res.append(entry(f"configs[3] x{B4} with the root-polynomial of degree 3 (13 terms)",
-                         "chain_kernel<CCM_ROOT, S/H, F32_LINEAR>", 24.0, float(B4) * H4 * W4,
+        res.append(entry(f"configs[3] x{B4} with the root-polynomial of degree 3 (13 terms; its fit's coefficients are "
+                         "beyond float32: the correction runs as a float64 pass into a staging image)",
+                         "ccm_f64_kernel<ROOT, 13> + chain_kernel<CCM_NONE, S/H, F32_LINEAR>", 24.0, float(B4) * H4 * W4,
                          timed(lambda: ctx.chain_run(d4b, img4.data_ptr(), out4.data_ptr()))))
         # configs[2]: colour-negative look of fresh data, percentile search + inversion + CCM
         orange = torch.tensor([1.0, 0.75, 0.55], device=dev)
