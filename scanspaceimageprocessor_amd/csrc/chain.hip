@@ -286,6 +286,8 @@ __device__ __forceinline__ void finish_and_store(const Px v, const ChainParams& 
 struct F64Coefs {
   double c[3][SS_MAX_CCM_TERMS];
 };
+// (the kernel finds it behind its first argument in the kernel-argument segment)
+static_assert(alignof(ChainParams) <= 8 && alignof(F64Coefs) == 8, "second kernel argument is not at sizeof(ChainParams) rounded up to 8");
 
 // A fit with nearly as many terms as swatches (22 terms, root-polynomials of degree 3 and 4 on 24 swatches) has
 // coefficients of size 10 ... 10^5 whose products with the terms cancel to a pixel of size 1: float32 keeps such a

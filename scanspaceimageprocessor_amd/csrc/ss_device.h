@@ -235,6 +235,35 @@ __device__ __forceinline__ V sroot3(V x) { return vcopysign(hw_exp2(hw_log2(vabs
 template <class V>
 __device__ __forceinline__ V sroot4(V x) { return vcopysign(hw_sqrt(hw_sqrt(vabs(x))), x); }
 
+// x <= k per lane as a mask in a scalar register pair of its own, and the select that reads it: the compare sits
+// ahead of the logarithm and exponential of its branch instead of right in front of the select (which, reading vcc
+// behind the compare that wrote it, waits for it), and several can be in flight.  Used by the plain tile kernels
+// (SG = true below: 0.3-0.4 % of their time, same bits); the kernels with more stages have no scalar registers to
+// spare and spill vector registers with it.
+__device__ __forceinline__ unsigned long long mask_le(float x, float k) {
+  unsigned long long m;
+  asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "s"(k), "v"(x));
+  return m;
+}
+// AFTER_TRANS: an operand may come straight from v_exp_f32 / v_log_f32, whose result needs a wait state before it is
+// read; the compiler cannot see into the asm, so the wait state is spelled out.
+template <bool AFTER_TRANS = false>
+__device__ __forceinline__ float select_by(unsigned long long m, float if_set, float if_clear) {
+  float r;
+  if constexpr (AFTER_TRANS) {
+    asm("s_nop 0\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  } else {
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  }
+  return r;
+}
+struct Mask2 { unsigned long long x, y; };
+__device__ __forceinline__ Mask2 mask_le(v2f v, float k) { return Mask2{mask_le(v.x, k), mask_le(v.y, k)}; }
+template <bool AFTER_TRANS = false>
+__device__ __forceinline__ v2f select_by(Mask2 m, v2f if_set, v2f if_clear) {
+  return v2f{select_by<AFTER_TRANS>(m.x, if_set.x, if_clear.x), select_by<AFTER_TRANS>(m.y, if_set.y, if_clear.y)};
+}
+
 // sRGB inverse EOTF (colour.cctf_encoding): linear -> encoded.  x ** p = exp2(p * log2 x) on the power
 // segment only (x > 0 there); everything else, negatives included, takes the linear segment.
 template <class V>
@@ -246,16 +275,30 @@ __device__ __forceinline__ V srgb_encode(V L) {
 
 // clip(encode(L), 0, 1) with the clip applied to the two branches, where it is the clamp output modifier of the
 // multiply / multiply-add that makes them (free), instead of an instruction of its own behind the select
-template <class V>
+template <class V, bool SG = false>
 __device__ __forceinline__ V srgb_encode_clip(V L) {
-  const V hi = fma_clip01(hw_exp2(hw_log2(L) * (1.0f / 2.4f)), 1.055f, -0.055f);
-  const V lo = mul_clip01(L, 12.92f);
-  return L <= (V)(0.0031308f) ? lo : hi;
+  if constexpr (SG) {
+    const auto m = mask_le(L, 0.0031308f);
+    const V hi = fma_clip01(hw_exp2(hw_log2(L) * (1.0f / 2.4f)), 1.055f, -0.055f);
+    const V lo = mul_clip01(L, 12.92f);
+    return select_by(m, lo, hi);
+  } else {
+    const V hi = fma_clip01(hw_exp2(hw_log2(L) * (1.0f / 2.4f)), 1.055f, -0.055f);
+    const V lo = mul_clip01(L, 12.92f);
+    return L <= (V)(0.0031308f) ? lo : hi;
+  }
 }
 
 // sRGB EOTF (colour.cctf_decoding): encoded -> linear
-template <class V>
+template <class V, bool SG = false>
 __device__ __forceinline__ V srgb_decode(V v) {
+  if constexpr (SG) {
+    const auto m = mask_le(v, 0.040449936f);
+    const V t = mad<V>(v, 1.0f / 1.055f, 0.055f / 1.055f);
+    const V hi = hw_exp2(hw_log2(t) * 2.4f);
+    const V lo = v * (1.0f / 12.92f);
+    return select_by<true>(m, lo, hi);
+  }
   const V t = mad<V>(v, 1.0f / 1.055f, 0.055f / 1.055f);
   const V hi = hw_exp2(hw_log2(t) * 2.4f);
   const V lo = v * (1.0f / 12.92f);
@@ -489,11 +532,11 @@ __device__ __forceinline__ PxT<V> shifted_linear(const PxT<V> lin, const LabFT<V
 }
 
 // clip(encode(.)) of it: what _lab_to_rgb returns for the edited pixel
-template <class V>
+template <class V, bool SG = false>
 __device__ __forceinline__ PxT<V> shifted_rgb(const PxT<V> lin, const LabFT<V> f, const V dfx, const V dfy, const V dfz,
                                               const ChainParams& P, RiskT<V>* risk = nullptr, float same_d_floor = 0.0f) {
   const PxT<V> o = shifted_linear(lin, f, dfx, dfy, dfz, risk, same_d_floor);
-  return PxT<V>{srgb_encode_clip(o.r), srgb_encode_clip(o.g), srgb_encode_clip(o.b)};
+  return PxT<V>{srgb_encode_clip<V, SG>(o.r), srgb_encode_clip<V, SG>(o.g), srgb_encode_clip<V, SG>(o.b)};
 }
 
 // ---- colour correction ---------------------------------------------------------------------
@@ -851,7 +894,7 @@ __device__ __forceinline__ PxT<V> front_decoded(PxT<V> p, const ChainParams& P, 
     }
     if (P.sh) return sh_on_rgb<true, V>(p, P, risk);
   }
-  return PxT<V>{srgb_decode(p.r), srgb_decode(p.g), srgb_decode(p.b)};
+  return PxT<V>{srgb_decode<V, PLAIN>(p.r), srgb_decode<V, PLAIN>(p.g), srgb_decode<V, PLAIN>(p.b)};
 }
 
 // ---- stage 5 pointwise part: unsharp mask on (Ln, blurred Ln) (editingTools.py:767-809) -------
@@ -917,7 +960,7 @@ __device__ __forceinline__ PxT<V> usm_on_rgb(const PxT<V> lin, const V Ln, const
   // one d for X, Y and Z and a pixel in [0, 1]: |d| <= floor / 4 keeps every |g(f + d) - g(f)| below the floor
   // (3 (1.0001 + d)^2 d <= 0.91 floor for floor <= 0.4)
   const float same_d_floor = (PLAIN && CHROMA == 0) ? risk_floor * 0.25f : 0.0f;
-  return shifted_rgb(lin, f, dfx, dfy, dfz, P, risk, same_d_floor);
+  return shifted_rgb<V, PLAIN>(lin, f, dfx, dfy, dfz, P, risk, same_d_floor);
 }
 
 // ---- stages 6-7: final clip, encoding, quantisation -------------------------------------------
@@ -941,9 +984,11 @@ __device__ __forceinline__ PxT<V> finish(PxT<V> p, const ChainParams& P) {
 // curve's constants (one rounding where the product behind the curve has two).  The caller truncates.
 template <class V>
 __device__ __forceinline__ V srgb_encode_scaled16(V L) {
+  // (only the plain tile kernels come here: masks in scalar register pairs, see mask_le)
+  const auto m = mask_le(L, 0.0031308f);
   const V hi = mad<V>(hw_exp2(hw_log2(L) * (1.0f / 2.4f)), (float)(1.055 * 65535.0), (float)(-0.055 * 65535.0));
   const V lo = L * (float)(12.92 * 65535.0);
-  return L <= (V)(0.0031308f) ? lo : hi;
+  return select_by(m, lo, hi);
 }
 template <class V>
 __device__ __forceinline__ PxT<V> finish_scaled16(const PxT<V> p) {
